@@ -1,0 +1,107 @@
+// Shared host/device helpers for the gfx950 speculative-decoding library.
+// Not part of the C-ABI (see include/specdec_hip.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/specdec_hip.h"
+
+namespace sd {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char* fmt, ...);
+void clear_error();
+
+#define SD_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::sd::set_error(__VA_ARGS__);      \
+      return 1;                          \
+    }                                    \
+  } while (0)
+
+#define SD_HIP_CHECK(expr)                                                   \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      ::sd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                      __FILE__, __LINE__);                                   \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+
+// A launch inside a stream capture cannot be followed by hipGetLastError-style
+// polling of a sticky error only; hipGetLastError is capture-safe.
+#define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
+
+inline int dtype_size(int dt) {
+  switch (dt) {
+    case SD_F32: return 4;
+    case SD_F16: return 2;
+    case SD_BF16: return 2;
+    case SD_I32: return 4;
+    case SD_I64: return 8;
+    case SD_U8: return 1;
+    case SD_FP8_E4M3: return 1;
+    default: return 0;
+  }
+}
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// ---- device helpers ---------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {
+  return __uint_as_float(static_cast<uint32_t>(b) << 16);
+}
+
+// round-to-nearest-even f32 -> bf16 that keeps NaN a NaN (plain cast lowers to
+// v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);
+  return *reinterpret_cast<uint16_t*>(&h);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// torch.argmax ordering: NaN is the maximum, ties go to the lower index.
+__device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) {
+  const bool vn = (v != v), bn = (bv != bv);
+  if (vn | bn) {
+    if (vn & bn) return i < bi;
+    return vn;
+  }
+  return (v > bv) | ((v == bv) & (i < bi));
+}
+
+__device__ __forceinline__ void wave_reduce_argmax(float& v, int& i) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    float ov = __shfl_xor(v, off, 64);
+    int oi = __shfl_xor(i, off, 64);
+    if (argmax_better(ov, oi, v, i)) {
+      v = ov;
+      i = oi;
+    }
+  }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace sd
