@@ -134,6 +134,121 @@ int sd_kv_append_masked(void* out_k, void* out_v,
                         int64_t base_sb, int64_t base_sh,
                         void* stream);
 
+/* ========================================================================
+ * Decoder forward + draft-then-verify loop
+ *
+ * The reference reaches the model through LanguageModel.generate_tokens
+ * (src/specdec/utils/interfaces.py:30-62; HFWrapper._generate_tokens_async,
+ * src/specdec/models/hf_wrappers.py:272-627 — one HF forward per generated token,
+ * argmax of the last position) and drives it from the step loop of
+ * SpeculativePipeline.generate_batch / generate (src/specdec/core/pipeline.py:
+ * 1984-3733, 984-1275). These entry points are what a ctypes binding of that path
+ * binds instead: a model instance over caller-owned weights and caches, a forward
+ * that appends to the KV cache in place, and one call per draft-then-verify step.
+ * ======================================================================== */
+
+enum sd_arch { SD_ARCH_LLAMA = 0, SD_ARCH_GPT2 = 1 };
+
+/* Per-layer weights. Linear weights are [out_features][in_features] row-major
+ * (HF nn.Linear layout), bf16. Biases / LayerNorm biases may be NULL (Llama). */
+typedef struct sd_layer_weights {
+  const void* attn_norm_w;  /* [d]  input_layernorm / ln_1 */
+  const void* attn_norm_b;  /* [d]  GPT-2 only */
+  const void* wqkv;         /* [(Hq+2*Hkv)*D][d]  q rows, then k rows, then v rows */
+  const void* bqkv;
+  const void* wo;           /* [d][Hq*D] */
+  const void* bo;
+  const void* mlp_norm_w;   /* [d]  post_attention_layernorm / ln_2 */
+  const void* mlp_norm_b;
+  const void* w_up;         /* Llama: [2*ff][d] gate rows then up rows; GPT-2: c_fc [ff][d] */
+  const void* b_up;
+  const void* w_down;       /* [d][ff] */
+  const void* b_down;
+} sd_layer_weights;
+
+typedef struct sd_model_config {
+  int arch;                 /* enum sd_arch */
+  int n_layers, d_model, n_heads, n_kv_heads, head_dim, d_ff, vocab, max_pos;
+  float norm_eps;
+  int weight_dtype;         /* SD_BF16 */
+  const void* tok_emb;      /* [vocab][d] */
+  const void* pos_emb;      /* [max_pos][d], GPT-2 only */
+  const void* final_norm_w; /* [d] */
+  const void* final_norm_b;
+  const void* lm_head;      /* [vocab][d] (may alias tok_emb) */
+  const float* rope_cos;    /* [max_pos][D/2] fp32, Llama only */
+  const float* rope_sin;
+  const sd_layer_weights* layers; /* host array [n_layers] (copied by sd_model_create) */
+} sd_model_config;
+
+typedef struct sd_model sd_model;
+
+/* Create a model over caller-owned device weights (borrowed for the model's life). */
+int sd_model_create(const sd_model_config* cfg, sd_model** out);
+int sd_model_destroy(sd_model* m);
+
+/* Scratch the forward needs (activations of one pass + argmax partials). */
+size_t sd_model_workspace_bytes(const sd_model* m);
+/* Bytes of ONE of the two cache tensors: [n_layers][B][Hkv][Lmax][D] bf16. */
+size_t sd_model_kv_bytes(const sd_model* m, int B, int Lmax);
+/* Attach caller-owned KV caches and workspace. */
+int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax,
+                  void* workspace, size_t workspace_bytes);
+
+/* One forward over M new tokens per batch row, appended to the KV cache in place.
+ *   tokens   : device int32, token (b,m) at tokens[b*tok_stride + m]
+ *   pos_base : device int32[B]; token (b,m) sits at position pos_base[b] + pos_off + m
+ *              and attends to cache positions 0 .. that position (its own K/V are
+ *              written first — the KV-append path of kv_append_ref, fused)
+ *   ids_out  : optional device int32, argmax of token (b,m) at ids_out[b*ids_stride+m]
+ *   logits_out: optional [B][M][vocab] (SD_BF16 | SD_F32)
+ *   skip_head: 1 = only fill the cache (prefill of all but the last token)
+ * B*M may exceed the 9 tokens one pass holds; the call then makes several passes. */
+int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride,
+                     const int32_t* pos_base, int pos_off, int B, int M,
+                     int32_t* ids_out, int ids_stride,
+                     void* logits_out, int logits_dtype, int skip_head, void* stream);
+
+/* ---- the step loop ------------------------------------------------------- */
+typedef struct sd_specdec sd_specdec;
+
+enum sd_emit_mode {
+  SD_EMIT_BONUS = 0,   /* generate_batch: base tokens t_0..t_{a-1} + bonus t_a (pipeline.py:3059-3292) */
+  SD_EMIT_DRAFT = 1    /* generate: draft tokens d_1..d_a, or t_0 if a == 0 (pipeline.py:1190-1235) */
+};
+
+/* Creation allocates the (tiny) device loop state and a pinned host mirror. Both
+ * models must be bound with the same B. */
+int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K, int emit_mode,
+                      sd_specdec** out);
+int sd_specdec_destroy(sd_specdec* s);
+
+/* (Re)initialise row b: `seq_len` tokens are final, the last two of them are
+ * (prev_tok, last_tok); caches must hold positions [0, seq_len-1) of the target and
+ * [0, seq_len-2] or more of the draft. Asynchronous on `stream`. */
+int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_tok, int last_tok,
+                       int active, void* stream);
+
+/* Enqueue ONE draft-then-verify step for all rows: K draft forwards (the first over
+ * (prev,last), the rest over one token), one verify forward over (last,d_1..d_K),
+ * the accept scan (wave ballot), the in-place state advance, and the copy of the
+ * step record to pinned host memory. Draft work goes to stream_draft, verify to
+ * stream_target, ordered by events; with use_graph=1 the whole step is captured
+ * into a hipGraph on first use and replayed afterwards. */
+int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_draft, int use_graph);
+
+/* Block until everything enqueued on `stream` is done (hipStreamSynchronize). */
+int sd_specdec_sync(sd_specdec* s, void* stream);
+
+/* Pinned host record of the last completed step, ints per row:
+ *   [0] accept_len  [1] n_new  [2] cur_len after the step
+ *   [3 .. 3+K]            emitted tokens (n_new valid, -1 padded)
+ *   [4+K .. 3+2K]         draft tokens d_1..d_K
+ *   [4+2K .. 4+3K]        target argmax t_0..t_K
+ * row stride = sd_specdec_record_ints(). */
+const int32_t* sd_specdec_record(const sd_specdec* s);
+int sd_specdec_record_ints(const sd_specdec* s);
+
 #ifdef __cplusplus
 }
 #endif

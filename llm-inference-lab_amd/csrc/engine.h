@@ -1,0 +1,30 @@
+// Engine-internal types: model instance and the device-side state of the
+// draft-then-verify loop. The C-ABI view of these is in include/specdec_hip.h.
+#pragma once
+
+#include <vector>
+
+#include "kernels.h"
+
+namespace sd {
+
+// device-resident loop state (all int32, B rows, K draft tokens per step)
+struct SpecState {
+  int B, K;
+  int32_t* cur_len;     // [B]   tokens whose KV is final in the target cache (= position of `last`)
+  int32_t* active;      // [B]   1 = row advances
+  int32_t* tok2;        // [B][2]   (prev, last): input of draft forward 0
+  int32_t* next_tok;    // [B]      input of draft forwards 1..K-1
+  int32_t* draft_ids;   // [B][2]   argmax ids of the current draft forward
+  int32_t* draft_tok;   // [B][K]   d_1..d_K
+  int32_t* verify_tok;  // [B][K+1] (last, d_1..d_K): input of the verify forward
+  int32_t* target_ids;  // [B][K+1] target argmax at each verify position
+  int32_t* accept_len;  // [B]
+  int32_t* n_new;       // [B]
+  int32_t* new_tok;     // [B][K+1] emitted tokens, -1 padded
+};
+
+int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);
+int launch_accept(const SpecState& s, int mode, hipStream_t st);
+
+}  // namespace sd

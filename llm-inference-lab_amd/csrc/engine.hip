@@ -1,0 +1,541 @@
+// Decoder forward orchestration and the draft-then-verify step for gfx950.
+//
+// Host-side C++ behind the C-ABI (include/specdec_hip.h). It enqueues the kernels
+// of gemv.hip / attention.hip / misc.hip on caller-provided HIP streams, never
+// synchronises, and is graph-capturable: all per-row dynamic quantities (lengths,
+// tokens) live in device memory and are read by the kernels.
+//
+// What it replaces in the reference: HFWrapper._generate_tokens_async
+// (hf_wrappers.py:272-627: one HF forward + argmax per generated token, the whole
+// prefix re-fed unless a KV cache is threaded through) and the device-facing half of
+// the step loop of SpeculativePipeline.generate_batch (pipeline.py:2306-2846: draft
+// stream / verify stream / event waits). The reference verifies by letting the base
+// model generate K tokens autoregressively (speculative_scheduler.py:192-199); here
+// the target scores all K+1 positions in ONE forward over (last, d_1..d_K), which
+// under greedy decoding yields the same accepted prefix and bonus token.
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "engine.h"
+
+struct sd_model {
+  sd_model_config cfg;
+  std::vector<sd_layer_weights> layers;
+  // bound storage
+  uint16_t* k_cache = nullptr;
+  uint16_t* v_cache = nullptr;
+  int B = 0, Lmax = 0;
+  // workspace carve
+  uint16_t* x = nullptr;     // [9][d]
+  uint16_t* q = nullptr;     // [9][Hq*D]
+  uint16_t* attn = nullptr;  // [9][Hq*D]
+  uint16_t* act = nullptr;   // [9][ff]
+  float* part_val = nullptr; // [9][512]
+  int* part_idx = nullptr;
+  int head_grid = 0;         // grid of the last lm_head launch (partials per token)
+};
+
+namespace sd {
+
+constexpr int kMaxPartials = 512;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t workspace_bytes(const sd_model_config& c) {
+  const size_t T = kGemvMaxT;
+  size_t n = 0;
+  n += align_up(T * c.d_model * 2, 256);
+  n += align_up(T * c.n_heads * c.head_dim * 2, 256) * 2;
+  n += align_up(T * c.d_ff * 2, 256);
+  n += align_up(T * kMaxPartials * 4, 256) * 2;
+  return n + 256;
+}
+
+// one pass: Bc rows x Mc tokens, Bc*Mc <= 9
+static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
+                        int pos_off, int b0, int Bc, int Mc, int32_t* ids_out, int ids_stride,
+                        void* logits_out, int logits_dtype, int logits_stride, int skip_head,
+                        hipStream_t st) {
+  const sd_model_config& c = m->cfg;
+  const int T = Bc * Mc;
+  const int d = c.d_model, Hq = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, ff = c.d_ff;
+  const bool llama = (c.arch == SD_ARCH_LLAMA);
+  const int pro = llama ? PRO_RMSNORM : PRO_LAYERNORM;
+
+  EmbedArgs e{};
+  e.tok_emb = c.tok_emb;
+  e.pos_emb = llama ? nullptr : c.pos_emb;
+  e.tokens = tokens + static_cast<size_t>(b0) * tok_stride;
+  e.tok_stride = tok_stride;
+  e.pos_base = pos_base + b0;
+  e.pos_off = pos_off;
+  e.M = Mc;
+  e.T = T;
+  e.d = d;
+  e.vocab = c.vocab;
+  e.max_pos = c.max_pos;
+  e.x = m->x;
+  if (int rc = launch_embed(e, st)) return rc;
+
+  const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+  for (int l = 0; l < c.n_layers; ++l) {
+    const sd_layer_weights& w = m->layers[l];
+    uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(b0) * Hkv * m->Lmax * D;
+    uint16_t* vc = m->v_cache + l * layer_kv + static_cast<size_t>(b0) * Hkv * m->Lmax * D;
+
+    GemvArgs g{};
+    g.T = T;
+    g.M = Mc;
+    g.pos_base = pos_base + b0;
+    g.pos_off = pos_off;
+    g.head_dim = D;
+    g.n_q_heads = Hq;
+    g.n_kv_heads = Hkv;
+    g.max_pos = c.max_pos;
+    g.l_max = m->Lmax;
+    g.out_dtype = SD_BF16;
+
+    // 1. norm + QKV projection + RoPE + in-place KV append
+    GemvArgs a1 = g;
+    a1.W = w.wqkv;
+    a1.bias = w.bqkv;
+    a1.N = (Hq + 2 * Hkv) * D;
+    a1.K = d;
+    a1.n_pairs = a1.N / 2;
+    a1.x = m->x;
+    a1.x_stride = d;
+    a1.prologue = pro;
+    a1.norm_w = w.attn_norm_w;
+    a1.norm_b = w.attn_norm_b;
+    a1.norm_eps = c.norm_eps;
+    a1.out = m->q;
+    a1.out_stride = Hq * D;
+    a1.rope_cos = llama ? c.rope_cos : nullptr;
+    a1.rope_sin = llama ? c.rope_sin : nullptr;
+    a1.k_cache = kc;
+    a1.v_cache = vc;
+    if (int rc = launch_gemv(a1, EPI_QKV_ROPE, st)) return rc;
+
+    // 2. attention of the Mc new positions over the appended cache
+    AttnArgs at{};
+    at.q = m->q;
+    at.k_cache = kc;
+    at.v_cache = vc;
+    at.out = m->attn;
+    at.pos_base = pos_base + b0;
+    at.pos_off = pos_off;
+    at.B = Bc;
+    at.M = Mc;
+    at.n_q_heads = Hq;
+    at.n_kv_heads = Hkv;
+    at.head_dim = D;
+    at.l_max = m->Lmax;
+    at.scale = 1.0f / sqrtf(static_cast<float>(D));
+    if (int rc = launch_attention(at, st)) return rc;
+
+    // 3. output projection + residual
+    GemvArgs a3 = g;
+    a3.W = w.wo;
+    a3.bias = w.bo;
+    a3.N = d;
+    a3.K = Hq * D;
+    a3.n_pairs = d / 2;
+    a3.x = m->attn;
+    a3.x_stride = Hq * D;
+    a3.prologue = PRO_NONE;
+    a3.out = m->x;
+    a3.out_stride = d;
+    if (int rc = launch_gemv(a3, EPI_RESID, st)) return rc;
+
+    // 4. norm + up projection (+ gate) + activation
+    GemvArgs a4 = g;
+    a4.W = w.w_up;
+    a4.bias = w.b_up;
+    a4.K = d;
+    a4.x = m->x;
+    a4.x_stride = d;
+    a4.prologue = pro;
+    a4.norm_w = w.mlp_norm_w;
+    a4.norm_b = w.mlp_norm_b;
+    a4.norm_eps = c.norm_eps;
+    a4.out = m->act;
+    a4.out_stride = ff;
+    if (llama) {
+      a4.N = 2 * ff;
+      a4.n_pairs = ff;
+      if (int rc = launch_gemv(a4, EPI_SWIGLU, st)) return rc;
+    } else {
+      a4.N = ff;
+      a4.n_pairs = ff / 2;
+      if (int rc = launch_gemv(a4, EPI_GELU, st)) return rc;
+    }
+
+    // 5. down projection + residual
+    GemvArgs a5 = g;
+    a5.W = w.w_down;
+    a5.bias = w.b_down;
+    a5.N = d;
+    a5.K = ff;
+    a5.n_pairs = d / 2;
+    a5.x = m->act;
+    a5.x_stride = ff;
+    a5.prologue = PRO_NONE;
+    a5.out = m->x;
+    a5.out_stride = d;
+    if (int rc = launch_gemv(a5, EPI_RESID, st)) return rc;
+  }
+  if (skip_head) return 0;
+
+  // final norm + lm_head with the argmax fused into the epilogue
+  GemvArgs h{};
+  h.W = c.lm_head;
+  h.N = c.vocab;
+  h.K = d;
+  h.n_pairs = (c.vocab + 1) / 2;
+  h.x = m->x;
+  h.x_stride = d;
+  h.T = T;
+  h.M = Mc;
+  h.prologue = pro;
+  h.norm_w = c.final_norm_w;
+  h.norm_b = c.final_norm_b;
+  h.norm_eps = c.norm_eps;
+  h.out = logits_out;
+  h.out_stride = logits_stride;
+  h.out_dtype = logits_dtype;
+  h.part_val = m->part_val;
+  h.part_idx = m->part_idx;
+  int ks = 1;
+  m->head_grid = gemv_grid(h, &ks);
+  if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
+  if (ids_out) {
+    if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, T, m->head_grid, Mc, ids_stride,
+                                        ids_out + static_cast<size_t>(b0) * ids_stride, st))
+      return rc;
+  }
+  return 0;
+}
+
+static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
+                         int pos_off, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
+                         int logits_dtype, int skip_head, hipStream_t st) {
+  SD_REQUIRE(m && m->k_cache && m->x, "forward: model not bound (sd_model_bind)");
+  SD_REQUIRE(B >= 1 && B <= m->B, "forward: B=%d exceeds bound batch %d", B, m->B);
+  SD_REQUIRE(M >= 1, "forward: M=%d", M);
+  SD_REQUIRE(tokens && pos_base, "forward: NULL tokens/pos_base");
+  const int esz = (logits_dtype == SD_F32) ? 4 : 2;
+  SD_REQUIRE(!logits_out || logits_dtype == SD_F32 || logits_dtype == SD_BF16, "forward: logits dtype %d", logits_dtype);
+  const int V = m->cfg.vocab;
+  if (M <= kGemvMaxT) {
+    const int Bc = kGemvMaxT / M;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = (B - b0 < Bc) ? B - b0 : Bc;
+      void* lo = logits_out ? static_cast<char*>(logits_out) + static_cast<size_t>(b0) * M * V * esz : nullptr;
+      if (int rc = forward_pass(m, tokens, tok_stride, pos_base, pos_off, b0, nb, M, ids_out, ids_stride, lo,
+                                logits_dtype, V, skip_head, st))
+        return rc;
+    }
+    return 0;
+  }
+  // long M (prefill): chunks of 9 positions, one row at a time, in position order
+  for (int b0 = 0; b0 < B; ++b0) {
+    for (int m0 = 0; m0 < M; m0 += kGemvMaxT) {
+      const int mc = (M - m0 < kGemvMaxT) ? M - m0 : kGemvMaxT;
+      void* lo = logits_out ? static_cast<char*>(logits_out) + (static_cast<size_t>(b0) * M + m0) * V * esz : nullptr;
+      if (int rc = forward_pass(m, tokens + m0, tok_stride, pos_base, pos_off + m0, b0, 1, mc,
+                                ids_out ? ids_out + m0 : nullptr, ids_stride, lo, logits_dtype, V, skip_head, st))
+        return rc;
+    }
+  }
+  return 0;
+}
+
+}  // namespace sd
+
+// ============================================================================ C-ABI
+using namespace sd;
+
+extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
+  clear_error();
+  SD_REQUIRE(cfg && out, "model_create: NULL argument");
+  SD_REQUIRE(cfg->arch == SD_ARCH_LLAMA || cfg->arch == SD_ARCH_GPT2, "model_create: arch %d", cfg->arch);
+  SD_REQUIRE(cfg->weight_dtype == SD_BF16, "model_create: only bf16 weights are supported (got %d)", cfg->weight_dtype);
+  SD_REQUIRE(cfg->n_layers > 0 && cfg->d_model > 0 && cfg->n_heads > 0 && cfg->n_kv_heads > 0 &&
+                 cfg->head_dim > 0 && cfg->d_ff > 0 && cfg->vocab > 0 && cfg->max_pos > 0,
+             "model_create: non-positive dimension");
+  SD_REQUIRE(cfg->d_model % 8 == 0 && cfg->d_ff % 8 == 0 && (cfg->n_heads * cfg->head_dim) % 8 == 0,
+             "model_create: d_model, d_ff and Hq*D must be multiples of 8");
+  SD_REQUIRE(cfg->head_dim % 2 == 0 && cfg->n_heads % cfg->n_kv_heads == 0, "model_create: head layout");
+  SD_REQUIRE(cfg->tok_emb && cfg->lm_head && cfg->final_norm_w && cfg->layers, "model_create: NULL weights");
+  if (cfg->arch == SD_ARCH_LLAMA) SD_REQUIRE(cfg->rope_cos && cfg->rope_sin, "model_create: Llama needs rope tables");
+  if (cfg->arch == SD_ARCH_GPT2) SD_REQUIRE(cfg->pos_emb && cfg->final_norm_b, "model_create: GPT-2 needs pos_emb and ln_f bias");
+  sd_model* m = new (std::nothrow) sd_model();
+  SD_REQUIRE(m, "model_create: out of memory");
+  m->cfg = *cfg;
+  m->layers.assign(cfg->layers, cfg->layers + cfg->n_layers);
+  m->cfg.layers = m->layers.data();
+  for (int l = 0; l < cfg->n_layers; ++l) {
+    const sd_layer_weights& w = m->layers[l];
+    if (!(w.attn_norm_w && w.wqkv && w.wo && w.mlp_norm_w && w.w_up && w.w_down)) {
+      delete m;
+      SD_REQUIRE(false, "model_create: layer %d has NULL weights", l);
+    }
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int sd_model_destroy(sd_model* m) {
+  delete m;
+  return 0;
+}
+
+extern "C" size_t sd_model_workspace_bytes(const sd_model* m) { return m ? workspace_bytes(m->cfg) : 0; }
+
+extern "C" size_t sd_model_kv_bytes(const sd_model* m, int B, int Lmax) {
+  if (!m || B <= 0 || Lmax <= 0) return 0;
+  return static_cast<size_t>(m->cfg.n_layers) * B * m->cfg.n_kv_heads * Lmax * m->cfg.head_dim * 2;
+}
+
+extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax, void* workspace,
+                             size_t workspace_bytes_) {
+  clear_error();
+  SD_REQUIRE(m && k_cache && v_cache && workspace, "model_bind: NULL argument");
+  SD_REQUIRE(B >= 1 && Lmax >= 1, "model_bind: B=%d Lmax=%d", B, Lmax);
+  SD_REQUIRE(workspace_bytes_ >= workspace_bytes(m->cfg), "model_bind: workspace too small");
+  SD_REQUIRE((reinterpret_cast<uintptr_t>(k_cache) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 15) == 0,
+             "model_bind: caches must be 16-byte aligned");
+  m->k_cache = static_cast<uint16_t*>(k_cache);
+  m->v_cache = static_cast<uint16_t*>(v_cache);
+  m->B = B;
+  m->Lmax = Lmax;
+  const sd_model_config& c = m->cfg;
+  const size_t T = kGemvMaxT;
+  char* p = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  m->x = reinterpret_cast<uint16_t*>(p);
+  p += align_up(T * c.d_model * 2, 256);
+  m->q = reinterpret_cast<uint16_t*>(p);
+  p += align_up(T * c.n_heads * c.head_dim * 2, 256);
+  m->attn = reinterpret_cast<uint16_t*>(p);
+  p += align_up(T * c.n_heads * c.head_dim * 2, 256);
+  m->act = reinterpret_cast<uint16_t*>(p);
+  p += align_up(T * c.d_ff * 2, 256);
+  m->part_val = reinterpret_cast<float*>(p);
+  p += align_up(T * kMaxPartials * 4, 256);
+  m->part_idx = reinterpret_cast<int*>(p);
+  return 0;
+}
+
+extern "C" int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
+                                int pos_off, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
+                                int logits_dtype, int skip_head, void* stream) {
+  clear_error();
+  return model_forward(m, tokens, tok_stride, pos_base, pos_off, B, M, ids_out, ids_stride, logits_out,
+                       logits_dtype, skip_head, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------- step loop
+struct sd_specdec {
+  sd_model* draft = nullptr;
+  sd_model* target = nullptr;
+  int B = 0, K = 0, mode = 0;
+  SpecState st{};
+  int32_t* dev_block = nullptr;   // all device state in one allocation
+  int32_t* dev_record = nullptr;  // [B][rec]
+  int32_t* host_record = nullptr; // pinned
+  int32_t* host_stage = nullptr;  // pinned staging for set_row
+  int rec = 0;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t graph_st_t = nullptr, graph_st_d = nullptr;
+  long steps = 0;
+};
+
+namespace sd {
+
+__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec, int rec_ints) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int K = s.K;
+  int32_t* r = rec + static_cast<size_t>(b) * rec_ints;
+  if (lane == 0) {
+    r[0] = s.accept_len[b];
+    r[1] = s.n_new[b];
+    r[2] = s.cur_len[b];
+  }
+  if (lane <= K) {
+    r[3 + lane] = s.new_tok[b * (K + 1) + lane];
+    r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
+  }
+  if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
+}
+
+static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
+  const int B = s->B, K = s->K;
+  const bool two = (st_d != st_t);
+  if (two) {
+    SD_HIP_CHECK(hipEventRecord(s->ev_fork, st_t));
+    SD_HIP_CHECK(hipStreamWaitEvent(st_d, s->ev_fork, 0));
+  }
+  // draft: forward 0 over (prev, last) at positions cur_len-1, cur_len; then one token each
+  for (int i = 0; i < K; ++i) {
+    const int M = (i == 0) ? 2 : 1;
+    const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
+    const int off = (i == 0) ? -1 : i;
+    if (int rc = model_forward(s->draft, toks, M, s->st.cur_len, off, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d))
+      return rc;
+    if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
+  }
+  if (two) {
+    SD_HIP_CHECK(hipEventRecord(s->ev_join, st_d));
+    SD_HIP_CHECK(hipStreamWaitEvent(st_t, s->ev_join, 0));
+  }
+  // verify: one forward over (last, d_1..d_K)
+  if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, B, K + 1, s->st.target_ids,
+                             K + 1, nullptr, SD_BF16, 0, st_t))
+    return rc;
+  if (int rc = launch_accept(s->st, s->mode, st_t)) return rc;
+  hipLaunchKernelGGL(pack_record_kernel, dim3(B), dim3(kWave), 0, st_t, s->st, s->dev_record, s->rec);
+  SD_LAUNCH_CHECK();
+  SD_HIP_CHECK(hipMemcpyAsync(s->host_record, s->dev_record, sizeof(int32_t) * B * s->rec, hipMemcpyDeviceToHost, st_t));
+  return 0;
+}
+
+}  // namespace sd
+
+extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K, int emit_mode, sd_specdec** out) {
+  clear_error();
+  SD_REQUIRE(draft && target && out, "specdec_create: NULL argument");
+  SD_REQUIRE(B >= 1 && K >= 1 && K <= 8, "specdec_create: B=%d K=%d (K in 1..8)", B, K);
+  SD_REQUIRE(B * (K + 1) <= 65535, "specdec_create: batch too large");
+  SD_REQUIRE(draft->B >= B && target->B >= B, "specdec_create: models must be bound with batch >= %d", B);
+  SD_REQUIRE(draft->cfg.vocab == target->cfg.vocab, "specdec_create: draft/target vocabularies differ (%d vs %d)",
+             draft->cfg.vocab, target->cfg.vocab);
+  SD_REQUIRE(emit_mode == SD_EMIT_BONUS || emit_mode == SD_EMIT_DRAFT, "specdec_create: emit_mode %d", emit_mode);
+  // verify of B rows must fit the passes of the target forward: any B works (tiled)
+  sd_specdec* s = new (std::nothrow) sd_specdec();
+  SD_REQUIRE(s, "specdec_create: out of memory");
+  s->draft = draft;
+  s->target = target;
+  s->B = B;
+  s->K = K;
+  s->mode = emit_mode;
+  s->rec = 5 + 3 * K;
+  const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1));
+  const size_t n_total = n_state + static_cast<size_t>(B) * s->rec;
+  hipError_t e = hipMalloc(&s->dev_block, n_total * sizeof(int32_t));
+  if (e != hipSuccess) {
+    delete s;
+    SD_REQUIRE(false, "specdec_create: hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  (void)hipMemset(s->dev_block, 0, n_total * sizeof(int32_t));
+  int32_t* p = s->dev_block;
+  SpecState& st = s->st;
+  st.B = B;
+  st.K = K;
+  st.cur_len = p; p += B;
+  st.active = p; p += B;
+  st.tok2 = p; p += 2 * B;
+  st.next_tok = p; p += B;
+  st.draft_ids = p; p += 2 * B;
+  st.draft_tok = p; p += static_cast<size_t>(B) * K;
+  st.verify_tok = p; p += static_cast<size_t>(B) * (K + 1);
+  st.target_ids = p; p += static_cast<size_t>(B) * (K + 1);
+  st.accept_len = p; p += B;
+  st.n_new = p; p += B;
+  st.new_tok = p; p += static_cast<size_t>(B) * (K + 1);
+  s->dev_record = p;
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * B * s->rec, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * 8, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+    sd_specdec_destroy(s);
+    SD_REQUIRE(false, "specdec_create: pinned memory / event creation failed");
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int sd_specdec_destroy(sd_specdec* s) {
+  if (!s) return 0;
+  if (s->exec) (void)hipGraphExecDestroy(s->exec);
+  if (s->graph) (void)hipGraphDestroy(s->graph);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->host_record) (void)hipHostFree(s->host_record);
+  if (s->host_stage) (void)hipHostFree(s->host_stage);
+  if (s->dev_block) (void)hipFree(s->dev_block);
+  delete s;
+  return 0;
+}
+
+extern "C" int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_tok, int last_tok, int active,
+                                  void* stream) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_set_row: NULL");
+  SD_REQUIRE(b >= 0 && b < s->B, "specdec_set_row: row %d out of range", b);
+  SD_REQUIRE(seq_len >= 1, "specdec_set_row: seq_len=%d (need at least one token)", seq_len);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // the staging slot of row b must not be rewritten while a previous copy is in flight
+  SD_HIP_CHECK(hipStreamSynchronize(st));
+  int32_t* h = s->host_stage + b * 8;
+  h[0] = seq_len - 1;  // cur_len: position of `last`
+  h[1] = active ? 1 : 0;
+  h[2] = prev_tok;
+  h[3] = last_tok;
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.cur_len + b, h + 0, 4, hipMemcpyHostToDevice, st));
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.active + b, h + 1, 4, hipMemcpyHostToDevice, st));
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.tok2 + 2 * b, h + 2, 8, hipMemcpyHostToDevice, st));
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.verify_tok + static_cast<size_t>(b) * (s->K + 1), h + 3, 4, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+extern "C" int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_draft, int use_graph) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_step: NULL");
+  hipStream_t st_t = static_cast<hipStream_t>(stream_target);
+  hipStream_t st_d = stream_draft ? static_cast<hipStream_t>(stream_draft) : st_t;
+  s->steps++;
+  if (!use_graph || s->steps == 1) {
+    // the first step always runs eagerly: it also performs the one-time kernel
+    // attribute setup that must not happen inside a capture
+    return enqueue_step(s, st_t, st_d);
+  }
+  if (s->exec && (s->graph_st_t != st_t || s->graph_st_d != st_d)) {
+    (void)hipGraphExecDestroy(s->exec);
+    (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+  }
+  if (!s->exec) {
+    SD_HIP_CHECK(hipStreamBeginCapture(st_t, hipStreamCaptureModeRelaxed));
+    const int rc = enqueue_step(s, st_t, st_d);
+    hipGraph_t g = nullptr;
+    const hipError_t ee = hipStreamEndCapture(st_t, &g);
+    if (rc != 0) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    SD_HIP_CHECK(ee);
+    s->graph = g;
+    SD_HIP_CHECK(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+    s->graph_st_t = st_t;
+    s->graph_st_d = st_d;
+  }
+  SD_HIP_CHECK(hipGraphLaunch(s->exec, st_t));
+  return 0;
+}
+
+extern "C" int sd_specdec_sync(sd_specdec* s, void* stream) {
+  clear_error();
+  (void)s;
+  SD_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" const int32_t* sd_specdec_record(const sd_specdec* s) { return s ? s->host_record : nullptr; }
+
+extern "C" int sd_specdec_record_ints(const sd_specdec* s) { return s ? s->rec : 0; }

@@ -1,0 +1,83 @@
+// Internal kernel-launch interfaces shared by the engine (not part of the C-ABI).
+#pragma once
+
+#include "common.h"
+
+namespace sd {
+
+// ---- skinny GEMM (gemv.hip) ---------------------------------------------------
+enum GemvPrologue { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };
+enum GemvEpilogue { EPI_QKV_ROPE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_ARGMAX = 4 };
+
+constexpr int kGemvMaxT = 9;  // tokens per pass (K+1 for K = 8)
+
+struct GemvArgs {
+  // weights: bf16 [N][K] row-major
+  const void* W;
+  const void* bias;  // bf16 [N] or null
+  int N, K;
+  int n_pairs;       // row pairs processed (see pair_rows)
+  // activations in: bf16 [T][x_stride]
+  const void* x;
+  int x_stride;
+  int T;             // tokens in this pass
+  int M;             // tokens per batch row (t = b*M + m)
+  // fused normalisation of x
+  int prologue;
+  const void* norm_w;
+  const void* norm_b;
+  float norm_eps;
+  // outputs
+  void* out;         // q buffer / residual stream / activation / logits (may be null for ARGMAX)
+  int out_stride;
+  int out_dtype;     // SD_BF16 | SD_F32 (logits only)
+  // QKV epilogue
+  int head_dim, n_q_heads, n_kv_heads;
+  const int32_t* pos_base;  // device [B]
+  int pos_off;
+  const float* rope_cos;    // [max_pos][head_dim/2] or null (no RoPE)
+  const float* rope_sin;
+  int max_pos;
+  void* k_cache;            // [B][n_kv_heads][l_max][head_dim] bf16
+  void* v_cache;
+  int l_max;
+  // ARGMAX epilogue: per-workgroup partials [T][grid]
+  float* part_val;
+  int* part_idx;
+};
+
+int gemv_tile_for(int T);
+int gemv_grid(const GemvArgs& a, int* ksplit_out);
+int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);
+
+// ---- attention over the appended KV cache (attention.hip) -------------------------
+struct AttnArgs {
+  const void* q;        // bf16 [T][n_q_heads*head_dim]
+  const void* k_cache;  // bf16 [B][n_kv_heads][l_max][head_dim]
+  const void* v_cache;
+  void* out;            // bf16 [T][n_q_heads*head_dim]
+  const int32_t* pos_base;
+  int pos_off;
+  int B, M;
+  int n_q_heads, n_kv_heads, head_dim, l_max;
+  float scale;
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+
+// ---- small kernels (misc.hip) -------------------------------------------------------
+struct EmbedArgs {
+  const void* tok_emb;   // bf16 [vocab][d]
+  const void* pos_emb;   // bf16 [max_pos][d] or null
+  const int32_t* tokens; // device, token (b,m) at tokens[b*tok_stride + m]
+  int tok_stride;
+  const int32_t* pos_base;
+  int pos_off, M, T, d, vocab, max_pos;
+  void* x;               // bf16 [T][d]
+};
+int launch_embed(const EmbedArgs& a, hipStream_t st);
+
+// reduce the per-workgroup argmax partials: ids[b*ids_stride + m] = argmax over grid
+int launch_argmax_finalize(const float* part_val, const int* part_idx, int T, int grid, int M,
+                           int ids_stride, int32_t* ids_out, hipStream_t st);
+
+}  // namespace sd

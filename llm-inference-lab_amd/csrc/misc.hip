@@ -1,0 +1,143 @@
+// Small kernels around the forward: embedding gather, argmax finalisation, and the
+// device-side control of the draft-then-verify loop (next draft token, accept scan,
+// in-place state advance).
+
+#include "kernels.h"
+#include "engine.h"
+
+namespace sd {
+
+// x[t][:] = tok_emb[clamp(token[t])][:] (+ pos_emb[pos][:] for GPT-2)
+// clamp = validate_and_clamp_tokens, /root/reference/src/specdec/utils/token_validation.py:15-78
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+  const int t = blockIdx.x;
+  const int b = t / a.M, m = t - b * a.M;
+  int tok = a.tokens[b * a.tok_stride + m];
+  tok = tok < 0 ? 0 : (tok >= a.vocab ? a.vocab - 1 : tok);
+  const uint4* src = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.tok_emb) + static_cast<size_t>(tok) * a.d);
+  uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(a.x) + static_cast<size_t>(t) * a.d);
+  const int nvec = a.d >> 3;
+  if (!a.pos_emb) {
+    for (int v = threadIdx.x; v < nvec; v += blockDim.x) dst[v] = src[v];
+    return;
+  }
+  int pos = a.pos_base[b] + a.pos_off + m;
+  pos = pos < 0 ? 0 : (pos >= a.max_pos ? a.max_pos - 1 : pos);
+  const uint4* ps = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.pos_emb) + static_cast<size_t>(pos) * a.d);
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+    const uint4 e = src[v], p = ps[v];
+    const uint32_t ew[4] = {e.x, e.y, e.z, e.w}, pw[4] = {p.x, p.y, p.z, p.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = __uint_as_float(ew[j] << 16) + __uint_as_float(pw[j] << 16);
+      const float hi = __uint_as_float(ew[j] & 0xffff0000u) + __uint_as_float(pw[j] & 0xffff0000u);
+      o[j] = static_cast<uint32_t>(float_to_bf16_bits(lo)) | (static_cast<uint32_t>(float_to_bf16_bits(hi)) << 16);
+    }
+    dst[v] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int launch_embed(const EmbedArgs& a, hipStream_t st) {
+  SD_REQUIRE(a.d % 8 == 0, "embed: d=%d must be a multiple of 8", a.d);
+  hipLaunchKernelGGL(embed_kernel, dim3(a.T), dim3(256), 0, st, a);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// wave-wide fold of one token's per-workgroup partials
+__device__ __forceinline__ int fold_partials(const float* pv, const int* pi, int grid, int lane) {
+  float v = -INFINITY;
+  int i = 0x7fffffff;
+  for (int s = lane; s < grid; s += kWave) {
+    const float sv = pv[s];
+    const int si = pi[s];
+    if (argmax_better(sv, si, v, i)) { v = sv; i = si; }
+  }
+  wave_reduce_argmax(v, i);
+  return i;
+}
+
+// ids[b*ids_stride + m] = argmax over the lm_head partials of token t = b*M + m
+__global__ __launch_bounds__(kWave) void argmax_finalize_kernel(const float* part_val, const int* part_idx,
+                                                                int grid, int M, int ids_stride,
+                                                                int32_t* ids) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int i = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
+  if (lane == 0) {
+    const int b = t / M, m = t - b * M;
+    ids[b * ids_stride + m] = i;
+  }
+}
+
+int launch_argmax_finalize(const float* part_val, const int* part_idx, int T, int grid, int M,
+                           int ids_stride, int32_t* ids_out, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_finalize_kernel, dim3(T), dim3(kWave), 0, st, part_val, part_idx, grid, M,
+                     ids_stride, ids_out);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- draft: token i of the proposal ------------------------------------------------
+// The draft forward produced M tokens per row; the last one's argmax is d_{i+1}.
+__global__ void draft_next_kernel(int M, int i, SpecState s) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.B) return;
+  const int d = s.draft_ids[b * 2 + (M - 1)];
+  s.draft_tok[b * s.K + i] = d;
+  s.verify_tok[b * (s.K + 1) + i + 1] = d;
+  s.next_tok[b] = d;
+}
+
+int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st) {
+  hipLaunchKernelGGL(draft_next_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, M, i, s);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- verify: accept scan + state advance ----------------------------------------------
+// One wave per batch row. t_m = argmax of the target at position m of (last, d_1..d_K);
+// lane k holds match[k] = (t_k == d_{k+1}); __ballot + ctz gives the longest accepted
+// prefix (the contract of verify_prefix_ref, reference.py:36-53, and of
+// LongestPrefixPolicy.accept_tokens, policies.py:156-180, in one instruction).
+// The row's state is advanced on the device for the common case so that the next step
+// can be launched without a host round trip; the host re-synchronises a row whenever
+// the reference's host-side rules (EOS cut, de-duplication, budget) say otherwise.
+__global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int K = s.K, M = K + 1;
+  const int my_t = (lane < M) ? s.target_ids[b * M + lane] : -1;
+  const bool match = (lane < K) && (my_t == s.draft_tok[b * K + lane]);
+  const unsigned long long m64 = __ballot(match);
+  const unsigned long long valid = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+  const unsigned long long miss = (~m64) & valid;
+  const int a = miss ? __builtin_ctzll(miss) : K;
+
+  // tokens emitted by this step
+  //   mode 0 (generate_batch, pipeline.py:3059-3292): base tokens t_0..t_{a-1} + bonus t_a
+  //   mode 1 (generate, pipeline.py:1190-1235): draft tokens d_1..d_a, or t_0 when a == 0
+  const int n_new = (mode == 0) ? a + 1 : (a > 0 ? a : 1);
+  if (lane < M) s.new_tok[b * M + lane] = (lane < n_new) ? my_t : -1;
+  const int last_new = __shfl(my_t, n_new - 1, 64);
+  const int prev_new = __shfl(my_t, n_new >= 2 ? n_new - 2 : 0, 64);
+  if (lane == 0) {
+    s.accept_len[b] = a;
+    s.n_new[b] = n_new;
+    if (s.active[b]) {
+      const int old_last = s.tok2[b * 2 + 1];
+      s.tok2[b * 2 + 0] = (n_new >= 2) ? prev_new : old_last;
+      s.tok2[b * 2 + 1] = last_new;
+      s.verify_tok[b * M + 0] = last_new;
+      s.cur_len[b] += n_new;
+    }
+  }
+}
+
+int launch_accept(const SpecState& s, int mode, hipStream_t st) {
+  SD_REQUIRE(s.K >= 1 && s.K <= 63, "accept: K=%d out of range 1..63", s.K);
+  hipLaunchKernelGGL(accept_kernel, dim3(s.B), dim3(kWave), 0, st, s, mode);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace sd

@@ -11,6 +11,13 @@ import os
 import threading
 from pathlib import Path
 
+# torch must be loaded BEFORE the library: the PyTorch-ROCm wheel bundles its own
+# libamdhip64.so.7 and the library has to bind to that same runtime instance (one
+# HIP context, torch's streams valid in our launches). Loading ours first pulls in
+# /opt/rocm's copy and the process ends up with two runtimes ("no ROCm-capable
+# device is detected" on the first launch).
+import torch  # noqa: F401
+
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libspecdec_hip.so"
 
@@ -49,6 +56,24 @@ SIGNATURES = {
          _c_void_p, _c_void_p,
          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_void_p],
     ),
+    # ---- decoder forward + step loop ----
+    "sd_model_create": (_c_int, [_c_void_p, _c_void_p]),
+    "sd_model_destroy": (_c_int, [_c_void_p]),
+    "sd_model_workspace_bytes": (_c_size, [_c_void_p]),
+    "sd_model_kv_bytes": (_c_size, [_c_void_p, _c_int, _c_int]),
+    "sd_model_bind": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_size]),
+    "sd_model_forward": (
+        _c_int,
+        [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+         _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
+    ),
+    "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "sd_specdec_destroy": (_c_int, [_c_void_p]),
+    "sd_specdec_set_row": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "sd_specdec_step": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int]),
+    "sd_specdec_sync": (_c_int, [_c_void_p, _c_void_p]),
+    "sd_specdec_record": (ctypes.POINTER(ctypes.c_int32), [_c_void_p]),
+    "sd_specdec_record_ints": (_c_int, [_c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,193 @@
+"""Python face of the decoder-forward / step-loop entry points of the C-ABI.
+
+Plumbing only: ctypes structs mirroring include/specdec_hip.h, torch tensors as the
+owners of device memory (weights, KV caches, workspaces), torch streams as the HIP
+streams. All arithmetic happens in csrc/.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+from .weights import ARCH_LLAMA, ModelConfig, ModelWeights
+
+_vp = ctypes.c_void_p
+
+
+class _LayerWeights(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "attn_norm_w", "attn_norm_b", "wqkv", "bqkv", "wo", "bo",
+        "mlp_norm_w", "mlp_norm_b", "w_up", "b_up", "w_down", "b_down")]
+
+
+class _ModelConfig(ctypes.Structure):
+    _fields_ = [
+        ("arch", ctypes.c_int),
+        ("n_layers", ctypes.c_int), ("d_model", ctypes.c_int), ("n_heads", ctypes.c_int),
+        ("n_kv_heads", ctypes.c_int), ("head_dim", ctypes.c_int), ("d_ff", ctypes.c_int),
+        ("vocab", ctypes.c_int), ("max_pos", ctypes.c_int),
+        ("norm_eps", ctypes.c_float),
+        ("weight_dtype", ctypes.c_int),
+        ("tok_emb", _vp), ("pos_emb", _vp), ("final_norm_w", _vp), ("final_norm_b", _vp),
+        ("lm_head", _vp), ("rope_cos", _vp), ("rope_sin", _vp),
+        ("layers", ctypes.POINTER(_LayerWeights)),
+    ]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(stream: Optional[torch.cuda.Stream], device) -> int:
+    return (stream or torch.cuda.current_stream(device)).cuda_stream
+
+
+class HipModel:
+    """A decoder (Llama or GPT-2 shaped) bound to its KV cache on one GPU."""
+
+    def __init__(self, weights: ModelWeights, batch: int, l_max: int, device: Optional[torch.device] = None):
+        self.lib = _abi.load()
+        self.cfg: ModelConfig = weights.config
+        dev = torch.device(device) if device is not None else weights.tok_emb.device
+        if dev.type != "cuda":
+            raise RuntimeError("HipModel needs weights on a GPU (PyTorch-ROCm device 'cuda'); there is no CPU path")
+        self.device = dev
+        self.weights = weights  # keeps the tensors (borrowed pointers) alive
+        for name, t in weights.tensors():
+            if t.device != dev:
+                raise RuntimeError(f"weight {name} is on {t.device}, expected {dev}")
+            want = torch.float32 if name.startswith("rope_") else torch.bfloat16
+            if t.dtype != want or not t.is_contiguous():
+                raise TypeError(f"weight {name}: need contiguous {want}, got {t.dtype} contiguous={t.is_contiguous()}")
+        c = self.cfg
+        self._layers = (_LayerWeights * c.n_layers)()
+        for i, l in enumerate(weights.layers):
+            for f, _ in _LayerWeights._fields_:
+                setattr(self._layers[i], f, _ptr(getattr(l, f)))
+        mc = _ModelConfig(
+            arch=c.arch, n_layers=c.n_layers, d_model=c.d_model, n_heads=c.n_heads, n_kv_heads=c.n_kv_heads,
+            head_dim=c.head_dim, d_ff=c.d_ff, vocab=c.vocab, max_pos=c.max_pos, norm_eps=c.norm_eps,
+            weight_dtype=_abi.SD_BF16, tok_emb=_ptr(weights.tok_emb), pos_emb=_ptr(weights.pos_emb),
+            final_norm_w=_ptr(weights.final_norm_w), final_norm_b=_ptr(weights.final_norm_b),
+            lm_head=_ptr(weights.lm_head), rope_cos=_ptr(weights.rope_cos), rope_sin=_ptr(weights.rope_sin),
+            layers=self._layers,
+        )
+        handle = _vp()
+        _abi.check(self.lib.sd_model_create(ctypes.byref(mc), ctypes.byref(handle)), "sd_model_create")
+        self.handle = handle
+        self.batch, self.l_max = int(batch), int(l_max)
+        kv_bytes = self.lib.sd_model_kv_bytes(self.handle, self.batch, self.l_max)
+        with torch.cuda.device(dev):
+            # [n_layers][B][Hkv][Lmax][D] bf16 — sized for 288 GB of HBM: no paging, no realign copies
+            self.k_cache = torch.zeros(kv_bytes // 2, dtype=torch.bfloat16, device=dev)
+            self.v_cache = torch.zeros(kv_bytes // 2, dtype=torch.bfloat16, device=dev)
+            self.workspace = torch.empty(self.lib.sd_model_workspace_bytes(self.handle), dtype=torch.uint8, device=dev)
+            _abi.check(self.lib.sd_model_bind(self.handle, self.k_cache.data_ptr(), self.v_cache.data_ptr(),
+                                              self.batch, self.l_max, self.workspace.data_ptr(),
+                                              self.workspace.numel()), "sd_model_bind")
+
+    def kv_view(self):
+        c = self.cfg
+        shape = (c.n_layers, self.batch, c.n_kv_heads, self.l_max, c.head_dim)
+        return self.k_cache.view(shape), self.v_cache.view(shape)
+
+    def forward(self, tokens: torch.Tensor, pos_base: torch.Tensor, pos_off: int = 0,
+                want_ids: bool = True, want_logits: bool = False, logits_dtype=torch.float32,
+                skip_head: bool = False, stream: Optional[torch.cuda.Stream] = None):
+        """tokens int32 [B][M] on the device, pos_base int32 [B]. Appends to the cache in place."""
+        assert tokens.dtype == torch.int32 and tokens.dim() == 2 and tokens.device == self.device
+        assert pos_base.dtype == torch.int32 and pos_base.shape == (tokens.shape[0],) and pos_base.device == self.device
+        B, M = tokens.shape
+        tokens = tokens.contiguous()
+        ids = torch.empty((B, M), dtype=torch.int32, device=self.device) if (want_ids and not skip_head) else None
+        logits = None
+        if want_logits and not skip_head:
+            logits = torch.empty((B, M, self.cfg.vocab), dtype=logits_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.sd_model_forward(
+                self.handle, tokens.data_ptr(), M, pos_base.data_ptr(), int(pos_off), B, M,
+                _ptr(ids), M, _ptr(logits),
+                _abi.SD_F32 if logits_dtype == torch.float32 else _abi.SD_BF16,
+                1 if skip_head else 0, _stream(stream, self.device))
+        _abi.check(rc, "sd_model_forward")
+        return ids, logits
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sd_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StepRecord:
+    """Host view of one completed step (pinned memory written by the device)."""
+
+    __slots__ = ("accept_len", "n_new", "cur_len", "new_tokens", "draft_tokens", "target_ids")
+
+    def __init__(self, arr: np.ndarray, K: int):
+        self.accept_len = arr[:, 0].copy()
+        self.n_new = arr[:, 1].copy()
+        self.cur_len = arr[:, 2].copy()
+        self.new_tokens = arr[:, 3:4 + K].copy()
+        self.draft_tokens = arr[:, 4 + K:4 + 2 * K].copy()
+        self.target_ids = arr[:, 4 + 2 * K:5 + 3 * K].copy()
+
+
+class HipSpecDec:
+    """The draft-then-verify step loop on the device (sd_specdec_*)."""
+
+    EMIT_BONUS, EMIT_DRAFT = 0, 1
+
+    def __init__(self, draft: HipModel, target: HipModel, batch: int, k: int, emit_mode: int = 0):
+        assert draft.device == target.device
+        self.lib = _abi.load()
+        self.draft, self.target = draft, target
+        self.device = target.device
+        self.B, self.K = int(batch), int(k)
+        handle = _vp()
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_create(draft.handle, target.handle, self.B, self.K, int(emit_mode),
+                                                  ctypes.byref(handle)), "sd_specdec_create")
+        self.handle = handle
+        self.rec_ints = self.lib.sd_specdec_record_ints(self.handle)
+        ptr = self.lib.sd_specdec_record(self.handle)
+        self._record = np.ctypeslib.as_array(ptr, shape=(self.B, self.rec_ints))
+
+    def set_row(self, b: int, seq_len: int, prev_tok: int, last_tok: int, active: bool = True,
+                stream: Optional[torch.cuda.Stream] = None):
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_set_row(self.handle, b, int(seq_len), int(prev_tok), int(last_tok),
+                                                   1 if active else 0, _stream(stream, self.device)), "sd_specdec_set_row")
+
+    def step(self, stream_target: Optional[torch.cuda.Stream] = None,
+             stream_draft: Optional[torch.cuda.Stream] = None, use_graph: bool = True):
+        with torch.cuda.device(self.device):
+            st = _stream(stream_target, self.device)
+            sd = stream_draft.cuda_stream if stream_draft is not None else None
+            _abi.check(self.lib.sd_specdec_step(self.handle, st, sd, 1 if use_graph else 0), "sd_specdec_step")
+
+    def sync(self, stream: Optional[torch.cuda.Stream] = None) -> StepRecord:
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_sync(self.handle, _stream(stream, self.device)), "sd_specdec_sync")
+        return StepRecord(self._record, self.K)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sd_specdec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
