@@ -189,7 +189,9 @@ int sd_model_destroy(sd_model* m);
 
 /* Scratch the forward needs (activations of one pass + argmax partials). */
 size_t sd_model_workspace_bytes(const sd_model* m);
-/* Bytes of ONE of the two cache tensors: [n_layers][B][Hkv][Lmax][D] bf16. */
+/* Bytes of ONE of the two cache tensors, bf16:
+ *   K: [n_layers][B][Hkv][Lmax][D]      V: [n_layers][B][Hkv][D][Lmax] (transposed)
+ * Lmax must be a multiple of 8. */
 size_t sd_model_kv_bytes(const sd_model* m, int B, int Lmax);
 /* Attach caller-owned KV caches and workspace. */
 int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax,

@@ -1,201 +1,226 @@
 // K-token parallel attention over the appended KV cache (draft decode: M = 1..2,
-// verify: M = K+1) for gfx950.
+// verify: M = K+1) for gfx950 — MFMA for the QK^T and PV contractions.
 //
 // Replaces what the reference gets from HF transformers' attention inside its k
 // sequential forwards (hf_wrappers.py:417/478): here all M new positions of a row are
 // scored against the cache in one pass, causally (query m sees keys 0 .. pos0+m).
 //
-// One workgroup = one (batch row, kv head, tile of up to 8 query rows); the query
-// rows of a kv head are its G = Hq/Hkv query heads x M positions, so K and V are
-// streamed once per tile instead of once per query head. K/V rows are read with
-// 16-byte loads, consecutive lanes on consecutive bytes of consecutive keys
-// (keys are contiguous in the [B][Hkv][Lmax][D] cache), the query tile is staged
-// in LDS pre-scaled, softmax is online over 64-key chunks (wave shuffles for
-// max/sum), and the PV accumulators live in registers.
+// Cache layout (owned by the engine):
+//   K: [B][Hkv][Lmax][D]   bf16 — a key is one contiguous row
+//   V: [B][Hkv][D][Lmax]   bf16 — TRANSPOSED, so that 8 consecutive keys of one
+//      channel are 16 contiguous bytes: exactly the MFMA operand shape of P·V.
+//      The append writes 2-byte elements either way (gemv.hip QKV epilogue), so the
+//      transpose is free at write time and saves an LDS transpose at read time.
 //
-// v1 uses VALU FMAs: at decode sizes this kernel moves <1% of a step's bytes.
+// One workgroup = one (batch row, kv head, tile of 16 query rows); the query rows of a
+// kv head are its G = Hq/Hkv query heads x M positions (15 rows for Llama-3.2-3B at
+// K = 4: one MFMA tile). The 4 waves split the keys in blocks of 32 (flash-decoding
+// inside the workgroup) and merge their (max, sum, O) partials through LDS.
+// Per block of 32 keys a wave does
+//   S^T[key][q] = K[key][:] . Q[q][:]      2 tiles x D/32  v_mfma_f32_16x16x32_bf16,
+//                                          A = K rows loaded straight from HBM/L2
+//                                          (16 B per lane), B = Q fragments (registers)
+//   online softmax on the 8 scores each lane holds for ITS query row (the key order of
+//   the two tiles is chosen so that a lane ends up with keys 8g..8g+7: its scores are,
+//   unpermuted, the A fragment of the next MFMA — no LDS, no shuffles for P)
+//   O[q][d] += P[q][key] . V[key][d]       D/16 MFMAs, B = V^T rows (16 B per lane)
+// All K and V loads of a block are issued before any arithmetic: one memory round
+// trip per block, and at decode lengths (<= 128 keys per wave) one per kernel.
 
 #include "kernels.h"
 
 namespace sd {
 
 constexpr int kAttnThreads = 256;
-constexpr int kAttnRows = 8;     // query rows per workgroup
-constexpr int kAttnChunk = 64;   // keys per online-softmax chunk
+constexpr int kAttnWaves = 4;
+constexpr int kAttnRows = 16;    // query rows per workgroup (MFMA tile)
+constexpr int kAttnBlock = 32;   // keys per block
 
-__global__ __launch_bounds__(kAttnThreads) void attention_kernel(const AttnArgs a) {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return static_cast<uint32_t>(float_to_bf16_bits(lo)) | (static_cast<uint32_t>(float_to_bf16_bits(hi)) << 16);
+}
+
+template <int D>
+__global__ __launch_bounds__(kAttnThreads) void attention_mfma_kernel(const AttnArgs a) {
+  constexpr int NKS = D / 32;  // k-steps of the QK^T contraction
+  constexpr int NDT = D / 16;  // 16-wide tiles of the output channels
   const int kvh = blockIdx.x, b = blockIdx.y, tile = blockIdx.z;
-  const int D = a.head_dim, G = a.n_q_heads / a.n_kv_heads, M = a.M;
+  const int G = a.n_q_heads / a.n_kv_heads, M = a.M;
   const int R = G * M;
   const int r_base = tile * kAttnRows;
   const int rows = min(kAttnRows, R - r_base);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int LPK = D >> 3;                    // lanes per key (8 elements each)
-  const int keys_per_pass = kAttnThreads / LPK;
+  const int g = lane >> 4, n = lane & 15;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* q_s = reinterpret_cast<float*>(smem);                 // [kAttnRows][D]
-  float* p_s = q_s + kAttnRows * D;                            // [kAttnRows][kAttnChunk]
-  float* alpha_s = p_s + kAttnRows * kAttnChunk;               // [kAttnRows]
-  float* m_s = alpha_s + kAttnRows;                            // running max
-  float* l_s = m_s + kAttnRows;                                // running sum
-  float* o_s = l_s + kAttnRows;                                // [4 waves][kAttnRows][D]
+  float* o_s = reinterpret_cast<float*>(smem);            // [waves][16][D]
+  float* m_s = o_s + kAttnWaves * kAttnRows * D;          // [waves][16]
+  float* l_s = m_s + kAttnWaves * kAttnRows;              // [waves][16]
 
-  const int pos0 = a.pos_base[b] + a.pos_off;  // position of query m = 0
-  const int n_keys = min(pos0 + M, a.l_max);   // keys visible to the last query
+  const int pos0 = a.pos_base[b] + a.pos_off;             // position of query m = 0
+  const int n_keys = max(0, min(pos0 + M, a.l_max));      // keys visible to the last query
+  const int n_blocks = (n_keys + kAttnBlock - 1) / kAttnBlock;
 
-  // stage the query tile (row r = g*M + m -> head kvh*G+g, token b*M+m), pre-scaled
-  const uint16_t* q = static_cast<const uint16_t*>(a.q);
+  // ---- Q fragments: lane (g, n) holds Q[row n][32 s + 8 g .. +8] for s < NKS -------
   const int qstride = a.n_q_heads * D;
-  for (int i = tid; i < kAttnRows * D; i += kAttnThreads) {
-    const int r = i / D, d = i - r * D;
-    float v = 0.f;
-    if (r < rows) {
-      const int rr = r_base + r, g = rr / M, m = rr - g * M;
-      v = bf16_bits_to_float(q[static_cast<size_t>(b * M + m) * qstride + (kvh * G + g) * D + d]) * a.scale;
+  u32x4 qf[NKS];
+  int my_m = 0;  // query position index of row n (for the causal mask)
+  {
+    const uint16_t* q = static_cast<const uint16_t*>(a.q);
+    const bool valid = n < rows;
+    const int rr = r_base + (valid ? n : 0);
+    const int gh = rr / M, m = rr - gh * M;
+    my_m = m;
+    const uint16_t* qrow = q + static_cast<size_t>(b * M + m) * qstride + (kvh * G + gh) * D + g * 8;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      if (valid) qf[s] = *reinterpret_cast<const u32x4*>(qrow + s * 32);
+      else qf[s] = u32x4{0u, 0u, 0u, 0u};
     }
-    q_s[i] = v;
   }
-  if (tid < kAttnRows) { m_s[tid] = -INFINITY; l_s[tid] = 0.f; }
-  __syncthreads();
 
   const uint16_t* kc = static_cast<const uint16_t*>(a.k_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max * D;
-  const uint16_t* vc = static_cast<const uint16_t*>(a.v_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max * D;
+  const uint16_t* vt = static_cast<const uint16_t*>(a.v_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * D * a.l_max;
 
-  // PV mapping: dv = 8-wide slice of D, kg = key group
-  const int DV = LPK;
-  const int dv = tid % DV, kg = tid / DV;
-  const int n_kg = kAttnThreads / DV;
-  float acc[kAttnRows][8];
+  f32x4_t oacc[NDT];
 #pragma unroll
-  for (int r = 0; r < kAttnRows; ++r)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+  for (int i = 0; i < NDT; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;  // for query row n (replicated over g)
 
-  for (int c0 = 0; c0 < n_keys; c0 += kAttnChunk) {
-    // ---- scores for keys [c0, c0+64) ------------------------------------------------
-    const int part = tid % LPK;
-    for (int kk = tid / LPK; kk < kAttnChunk; kk += keys_per_pass) {
-      const int key = c0 + kk;
-      float kf[8];
-      if (key < n_keys) {
-        const uint4 kv = *reinterpret_cast<const uint4*>(kc + static_cast<size_t>(key) * D + part * 8);
-        const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+  const int my_limit = pos0 + my_m;  // last key this lane's query may see
+
+  for (int blk = wave; blk < n_blocks; blk += kAttnWaves) {
+    const int key0 = blk * kAttnBlock;
+    // ---- issue every load of the block -------------------------------------------
+    // S^T tile u (u = 0,1): MFMA row i (= lane n) is key  key0 + 8*(i>>2) + 4*u + (i&3)
+    u32x4 kf[2][NKS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          kf[2 * j] = __uint_as_float(w[j] << 16);
-          kf[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-        }
-      } else {
+    for (int u = 0; u < 2; ++u) {
+      int key = key0 + 8 * (n >> 2) + 4 * u + (n & 3);
+      if (key >= a.l_max) key = a.l_max - 1;  // stay inside the cache; masked below
+      const uint16_t* krow = kc + static_cast<size_t>(key) * D + g * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kf[j] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < kAttnRows; ++r) {
-        const float4 qa = *reinterpret_cast<const float4*>(q_s + r * D + part * 8);
-        const float4 qb = *reinterpret_cast<const float4*>(q_s + r * D + part * 8 + 4);
-        float s = qa.x * kf[0] + qa.y * kf[1] + qa.z * kf[2] + qa.w * kf[3] +
-                  qb.x * kf[4] + qb.y * kf[5] + qb.z * kf[6] + qb.w * kf[7];
-        for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, 64);
-        if (part == 0) {
-          // causal mask: row r is query m, which sees keys <= pos0 + m
-          const int rr = r_base + r, m = rr % M;
-          const bool vis = (r < rows) && (key < n_keys) && (key <= pos0 + m);
-          p_s[r * kAttnChunk + kk] = vis ? s : -INFINITY;
-        }
-      }
+      for (int s = 0; s < NKS; ++s) kf[u][s] = *reinterpret_cast<const u32x4*>(krow + s * 32);
     }
-    __syncthreads();
-    // ---- online softmax: wave w owns rows w, w+4 ------------------------------------
-    for (int r = wave; r < kAttnRows; r += kAttnThreads / kWave) {
-      const float s = p_s[r * kAttnChunk + lane];
-      const float mx = wave_reduce_max(s);
-      const float m_old = m_s[r];
-      const float m_new = fmaxf(m_old, mx);
-      float p = 0.f, alpha = 1.f;
-      if (m_new > -INFINITY) {
-        p = (s > -INFINITY) ? __expf(s - m_new) : 0.f;
-        alpha = (m_old > -INFINITY) ? __expf(m_old - m_new) : 0.f;
-      }
-      const float sum = wave_reduce_sum(p);
-      p_s[r * kAttnChunk + lane] = p;
-      if (lane == 0) {
-        alpha_s[r] = alpha;
-        m_s[r] = m_new;
-        l_s[r] = l_s[r] * alpha + sum;
-      }
+    // V^T fragment of channel tile i: lane (g, n) holds V^T[16 i + n][key0 + 8 g .. +8]
+    u32x4 vf[NDT];
+    {
+      int kofs = key0 + 8 * g;
+      if (kofs + 8 > a.l_max) kofs = a.l_max - 8;  // l_max % 8 == 0 (checked by the host)
+      const uint16_t* vrow = vt + static_cast<size_t>(n) * a.l_max + kofs;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) vf[i] = *reinterpret_cast<const u32x4*>(vrow + static_cast<size_t>(16 * i) * a.l_max);
     }
-    __syncthreads();
-    // ---- PV --------------------------------------------------------------------------
+    // ---- S^T = K Q^T -----------------------------------------------------------------
+    f32x4_t st[2];
 #pragma unroll
-    for (int r = 0; r < kAttnRows; ++r) {
-      const float al = alpha_s[r];
+    for (int u = 0; u < 2; ++u) {
+      st[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[r][j] *= al;
+      for (int s = 0; s < NKS; ++s)
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[u][s]),
+                                                        __builtin_bit_cast(bf16x8_t, qf[s]), st[u], 0, 0, 0);
     }
-    for (int kk = kg; kk < kAttnChunk; kk += n_kg) {
-      const int key = c0 + kk;
-      if (key < n_keys) {
-        const uint4 vv = *reinterpret_cast<const uint4*>(vc + static_cast<size_t>(key) * D + dv * 8);
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-        float vf[8];
+    // lane (g, n) now holds, for query row n, the scores of keys key0 + 8g + (4u + r)
+    float sc[8];
+    float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vf[2 * j] = __uint_as_float(w[j] << 16);
-          vf[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-        }
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < kAttnRows; ++r) {
-          const float p = p_s[r * kAttnChunk + kk];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[r][j] += p * vf[j];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 8 * g + 4 * u + r;
+        const bool vis = (key <= my_limit) && (key < n_keys);
+        const float v = vis ? st[u][r] * a.scale : -INFINITY;
+        sc[4 * u + r] = v;
+        mx = fmaxf(mx, v);
       }
+    // row max / sum across the 4 lane groups that share n
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float alpha = 1.f, psum = 0.f;
+    float p[8];
+    if (m_new > -INFINITY) {
+      alpha = (m_run > -INFINITY) ? __expf(m_run - m_new) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[j] = (sc[j] > -INFINITY) ? __expf(sc[j] - m_new) : 0.f;
+        psum += p[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] = 0.f;
     }
-    __syncthreads();
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // P as the A operand: lane (g, n = q) holds P[q][key0 + 8g + j], j = 0..7
+    const u32x4 pf = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+    // rescale O: lane (g, n = d) holds O[q = 4g + r][d]; alpha of row q lives in lane q
+    float al[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) al[r] = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[i][r] *= al[r];
+      oacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf),
+                                                        __builtin_bit_cast(bf16x8_t, vf[i]), oacc[i], 0, 0, 0);
+    }
   }
 
-  // ---- fold the key groups: lanes that share dv inside a wave, then the 4 waves ------
-#pragma unroll
-  for (int r = 0; r < kAttnRows; ++r)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = acc[r][j];
-      for (int off = DV; off < kWave; off <<= 1) v += __shfl_xor(v, off, 64);
-      acc[r][j] = v;
-    }
-  if (lane < DV) {
-#pragma unroll
-    for (int r = 0; r < kAttnRows; ++r)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o_s[(wave * kAttnRows + r) * D + lane * 8 + j] = acc[r][j];
+  // ---- merge the 4 waves ----------------------------------------------------------------
+  if (g == 0) {
+    m_s[wave * kAttnRows + n] = m_run;
+    l_s[wave * kAttnRows + n] = l_run;
   }
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o_s[(wave * kAttnRows + 4 * g + r) * D + 16 * i + n] = oacc[i][r];
   __syncthreads();
   uint16_t* out = static_cast<uint16_t*>(a.out);
   for (int i = tid; i < rows * D; i += kAttnThreads) {
     const int r = i / D, d = i - r * D;
-    float v = 0.f;
+    float mm = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < kAttnThreads / kWave; ++w) v += o_s[(w * kAttnRows + r) * D + d];
-    const float l = l_s[r];
-    v = (l > 0.f) ? v / l : 0.f;
-    const int rr = r_base + r, g = rr / M, m = rr - g * M;
-    out[static_cast<size_t>(b * M + m) * qstride + (kvh * G + g) * D + d] = float_to_bf16_bits(v);
+    for (int w = 0; w < kAttnWaves; ++w) mm = fmaxf(mm, m_s[w * kAttnRows + r]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < kAttnWaves; ++w) {
+      const float mw = m_s[w * kAttnRows + r];
+      const float f = (mw > -INFINITY) ? __expf(mw - mm) : 0.f;
+      num += f * o_s[(w * kAttnRows + r) * D + d];
+      den += f * l_s[w * kAttnRows + r];
+    }
+    const float v = (den > 0.f) ? num / den : 0.f;
+    const int rr = r_base + r, gh = rr / M, m = rr - gh * M;
+    out[static_cast<size_t>(b * M + m) * qstride + (kvh * G + gh) * D + d] = float_to_bf16_bits(v);
   }
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t st) {
-  SD_REQUIRE(a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256,
-             "attention: head_dim %d not in {32,64,128,256}", a.head_dim);
+  SD_REQUIRE(a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128,
+             "attention: head_dim %d not in {32,64,128}", a.head_dim);
   SD_REQUIRE(a.n_kv_heads > 0 && a.n_q_heads % a.n_kv_heads == 0, "attention: Hq %% Hkv != 0");
   SD_REQUIRE(a.B >= 1 && a.M >= 1, "attention: empty batch");
+  SD_REQUIRE(a.l_max % 8 == 0 && a.l_max >= 8, "attention: l_max=%d must be a multiple of 8", a.l_max);
   const int G = a.n_q_heads / a.n_kv_heads;
   const int R = G * a.M;
   const int tiles = (R + kAttnRows - 1) / kAttnRows;
   const int D = a.head_dim;
-  const size_t smem = sizeof(float) * (static_cast<size_t>(kAttnRows) * D + kAttnRows * kAttnChunk +
-                                       3 * kAttnRows + 4 * kAttnRows * D);
-  hipLaunchKernelGGL(attention_kernel, dim3(a.n_kv_heads, a.B, tiles), dim3(kAttnThreads), smem, st, a);
+  const size_t smem = sizeof(float) * (static_cast<size_t>(kAttnWaves) * kAttnRows * D + 2 * kAttnWaves * kAttnRows);
+  const dim3 grid(a.n_kv_heads, a.B, tiles), block(kAttnThreads);
+  switch (D) {
+    case 32: hipLaunchKernelGGL(attention_mfma_kernel<32>, grid, block, smem, st, a); break;
+    case 64: hipLaunchKernelGGL(attention_mfma_kernel<64>, grid, block, smem, st, a); break;
+    default: hipLaunchKernelGGL(attention_mfma_kernel<128>, grid, block, smem, st, a); break;
+  }
   SD_LAUNCH_CHECK();
   return 0;
 }

@@ -5,49 +5,48 @@
 // from HBM per forward — this kernel IS the decode HBM roofline: its algorithmic
 // bytes are N*K*2 and everything else (x, epilogue) is L2/LDS traffic.
 //
-// Structure (MI355X-first, not a translation of anything in the reference, whose
-// forward lives in HF transformers — hf_wrappers.py:417/478):
-//   * one wave owns a PAIR of output rows at a time and all 64 lanes stride along K
-//     with global_load_dwordx4: every wave-instruction moves 1 KiB of contiguous
-//     weight bytes (full 128-B lines, no fragment-shaped loads);
-//   * the T activation rows are staged ONCE per workgroup into LDS as bf16 (with
-//     the RMSNorm / LayerNorm fused into the staging pass), and every 16-byte x
-//     vector read from LDS is used for both rows of the pair;
-//   * products use v_dot2c_f32_bf16 (2 MACs per lane-op, fp32 accumulate), so the
-//     VALU stays far from being the limiter;
-//   * loads are software-pipelined in two register buffers of 8 dwordx4 each:
-//     16 KiB in flight per wave, 64 KiB per CU;
-//   * the grid is sized to the chip (256 CUs), workgroups walk the row pairs with a
-//     grid stride so x is staged once per workgroup, and for the small matrices of
-//     Llama-3.2-1B/3B the K dimension is split over the waves of a workgroup
-//     (KSPLIT) so that every CU gets the same number of bytes;
-//   * the pair structure serves the fused epilogues: RoPE rotates rows (i, i+D/2)
-//     of a head, SwiGLU combines (gate_n, up_n), residual/logit stores write the
-//     two adjacent columns (2p, 2p+1) as one dword.
+// Structure (MI355X-first; the reference has no such kernel, its forward lives in HF
+// transformers — hf_wrappers.py:417/478):
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand (16 rows x 32 k) and
+//     the tokens as the B operand (32 k x 16 token columns, columns >= T are zero).
+//     One MFMA retires 1 KiB of weights in 16 cycles, so the matrix pipe is idle most
+//     of the time and the kernel stays bandwidth-bound for every T up to 16 (a first
+//     VALU v_dot2c version was issue-bound at T = 5: v_dot2c_f32_bf16 is quarter rate);
+//   * each lane loads its A fragment straight from HBM into VGPRs with one
+//     global_load_dwordx4 (nt): lane (g = lane>>4, n = lane&15) reads 16 bytes of row n
+//     at k = 32*step + 8*g, i.e. a wave-instruction covers 16 rows x 64 contiguous
+//     bytes and consecutive steps continue each row. No LDS round trip for weights;
+//   * latency is hidden by OCCUPANCY, not by a software pipeline: a workgroup is 16
+//     waves (one per CU, 4 per SIMD); every wave issues a batch of up to 16
+//     independent 1-KiB loads (16 KiB per wave, 256 KiB per CU in flight), waits for
+//     them once, and runs its 16 MFMAs. (A two-buffer pipeline inside 4-wave
+//     workgroups lost half its depth to hipcc's conservative vmcnt(0) at the loop
+//     back-edge; this form needs no counted waits.)
+//   * the T activation rows are staged ONCE per CU into LDS as bf16, with the
+//     RMSNorm / LayerNorm fused into the staging pass; B fragments are ds_read_b128;
+//   * work split: every workgroup owns a CONTIGUOUS range of ceil(pairs/256) row
+//     pairs — equal bytes per CU for any N — cut into n_tiles tiles of <= 8 pairs
+//     (16 MFMA rows); the 16 waves take (tile, K-slice) units, ksplit = 16 / n_tiles
+//     slices per tile, and the slices' partial 16x16 tiles are summed through LDS
+//     (one barrier per round of 16 units);
+//   * a "pair" is what the fused epilogue needs in one place: rows (i, i+D/2) of a
+//     head for RoPE, (gate_n, up_n) for SwiGLU, adjacent columns (2p, 2p+1) for the
+//     residual / logits stores. Rows 0..7 of a tile are the first rows of its
+//     pairs, rows 8..15 the second rows.
 
 #include "kernels.h"
 
 namespace sd {
 
-constexpr int kGemvThreads = 256;
-constexpr int kGemvWaves = kGemvThreads / kWave;
-constexpr int kChunk = 4;  // k-steps (of 64 lanes x 8 elements) per register buffer
+constexpr int kGemvThreads = 1024;
+constexpr int kGemvWaves = kGemvThreads / kWave;  // 16 waves: 4 per SIMD
+constexpr int kBatch = 12;                        // loads in flight per lane
+constexpr int kTilePairs = 8;
+constexpr int kXPad = 8;                          // bf16 elements of padding per staged x row
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w),
-                                         __builtin_bit_cast(bf16x2_t, x), acc, false);
-}
-
-__device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc) {
-  acc = dot2(w.x, x.x, acc);
-  acc = dot2(w.y, x.y, acc);
-  acc = dot2(w.z, x.z, acc);
-  acc = dot2(w.w, x.w, acc);
-  return acc;
-}
 
 __device__ __forceinline__ float gelu_new(float x) {
   // GPT-2 "gelu_new": 0.5 x (1 + tanh( sqrt(2/pi) (x + 0.044715 x^3) ))
@@ -73,99 +72,79 @@ __device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int
 }
 
 // ------------------------------------------------------------------------------
-// staging of x into LDS (bf16 [T][K]) with the fused normalisation
+// staging of x into LDS (bf16 [T][K + pad]) with the fused normalisation
 // ------------------------------------------------------------------------------
-template <int TT>
-__device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, float* red) {
+__device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP, float* red) {
   const int K = a.K, T = a.T;
   const int tid = threadIdx.x;
   const int nvec = K >> 3;
   const uint16_t* xin = static_cast<const uint16_t*>(a.x);
+  const int lane = tid & 63, wave = tid >> 6;
 
-  if (a.prologue == PRO_NONE) {
-    for (int t = 0; t < T; ++t) {
-      const uint4* src = reinterpret_cast<const uint4*>(xin + static_cast<size_t>(t) * a.x_stride);
-      uint4* dst = reinterpret_cast<uint4*>(xs + static_cast<size_t>(t) * K);
-      for (int v = tid; v < nvec; v += kGemvThreads) dst[v] = src[v];
-    }
-    __syncthreads();
-    return;
-  }
-
-  // pass 1: raw copy + per-token sum / sum of squares
-  float s1[TT], s2[TT];
-#pragma unroll
-  for (int t = 0; t < TT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    if (t < T) {
-      const uint4* src = reinterpret_cast<const uint4*>(xin + static_cast<size_t>(t) * a.x_stride);
-      uint4* dst = reinterpret_cast<uint4*>(xs + static_cast<size_t>(t) * K);
-      for (int v = tid; v < nvec; v += kGemvThreads) {
-        const uint4 q = src[v];
-        dst[v] = q;
+  for (int t = 0; t < T; ++t) {
+    const uint4* src = reinterpret_cast<const uint4*>(xin + static_cast<size_t>(t) * a.x_stride);
+    uint4* dst = reinterpret_cast<uint4*>(xs + static_cast<size_t>(t) * KP);
+    float s1 = 0.f, s2 = 0.f;
+    for (int v = tid; v < nvec; v += kGemvThreads) {
+      const uint4 q = src[v];
+      dst[v] = q;
+      if (a.prologue != PRO_NONE) {
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-          s1[t] += lo + hi;
-          s2[t] += lo * lo + hi * hi;
+          s1 += lo + hi;
+          s2 += lo * lo + hi * hi;
         }
       }
     }
-  }
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    if (t < T) {
-      const float a1 = wave_reduce_sum(s1[t]);
-      const float a2 = wave_reduce_sum(s2[t]);
+    if (a.prologue != PRO_NONE) {
+      s1 = wave_reduce_sum(s1);
+      s2 = wave_reduce_sum(s2);
       if (lane == 0) {
-        red[(wave * TT + t) * 2 + 0] = a1;
-        red[(wave * TT + t) * 2 + 1] = a2;
+        red[(t * kGemvWaves + wave) * 2 + 0] = s1;
+        red[(t * kGemvWaves + wave) * 2 + 1] = s2;
       }
     }
   }
   __syncthreads();
+  if (a.prologue == PRO_NONE) return;
   // pass 2: normalise in place. HF LlamaRMSNorm: weight * (x * rsqrt(var+eps)).to(bf16);
   // GPT-2 LayerNorm: (x-mean)*rsqrt(var+eps)*w + b computed in fp32, rounded once.
   const uint16_t* nw = static_cast<const uint16_t*>(a.norm_w);
   const uint16_t* nb = static_cast<const uint16_t*>(a.norm_b);
   const float invK = 1.0f / static_cast<float>(K);
+  for (int t = 0; t < T; ++t) {
+    float sum = 0.f, sq = 0.f;
 #pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    if (t < T) {
-      float sum = 0.f, sq = 0.f;
-#pragma unroll
-      for (int w = 0; w < kGemvWaves; ++w) {
-        sum += red[(w * TT + t) * 2 + 0];
-        sq += red[(w * TT + t) * 2 + 1];
+    for (int w = 0; w < kGemvWaves; ++w) {
+      sum += red[(t * kGemvWaves + w) * 2 + 0];
+      sq += red[(t * kGemvWaves + w) * 2 + 1];
+    }
+    uint16_t* row = xs + static_cast<size_t>(t) * KP;
+    if (a.prologue == PRO_RMSNORM) {
+      const float rs = rsqrtf(sq * invK + a.norm_eps);
+      for (int k = tid * 2; k < K; k += kGemvThreads * 2) {
+        const uint32_t xv = *reinterpret_cast<const uint32_t*>(row + k);
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(nw + k);
+        const float x0 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xv << 16) * rs));
+        const float x1 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xv & 0xffff0000u) * rs));
+        const uint16_t o0 = float_to_bf16_bits(x0 * __uint_as_float(wv << 16));
+        const uint16_t o1 = float_to_bf16_bits(x1 * __uint_as_float(wv & 0xffff0000u));
+        *reinterpret_cast<uint32_t*>(row + k) = static_cast<uint32_t>(o0) | (static_cast<uint32_t>(o1) << 16);
       }
-      uint16_t* row = xs + static_cast<size_t>(t) * K;
-      if (a.prologue == PRO_RMSNORM) {
-        const float rs = rsqrtf(sq * invK + a.norm_eps);
-        for (int k = tid * 2; k < K; k += kGemvThreads * 2) {
-          const uint32_t xv = *reinterpret_cast<const uint32_t*>(row + k);
-          const uint32_t wv = *reinterpret_cast<const uint32_t*>(nw + k);
-          const float x0 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xv << 16) * rs));
-          const float x1 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xv & 0xffff0000u) * rs));
-          const uint16_t o0 = float_to_bf16_bits(x0 * __uint_as_float(wv << 16));
-          const uint16_t o1 = float_to_bf16_bits(x1 * __uint_as_float(wv & 0xffff0000u));
-          *reinterpret_cast<uint32_t*>(row + k) = static_cast<uint32_t>(o0) | (static_cast<uint32_t>(o1) << 16);
-        }
-      } else {  // PRO_LAYERNORM
-        const float mean = sum * invK;
-        const float var = fmaxf(sq * invK - mean * mean, 0.f);
-        const float rs = rsqrtf(var + a.norm_eps);
-        for (int k = tid * 2; k < K; k += kGemvThreads * 2) {
-          const uint32_t xv = *reinterpret_cast<const uint32_t*>(row + k);
-          const uint32_t wv = *reinterpret_cast<const uint32_t*>(nw + k);
-          const uint32_t bv = *reinterpret_cast<const uint32_t*>(nb + k);
-          const float y0 = (__uint_as_float(xv << 16) - mean) * rs * __uint_as_float(wv << 16) + __uint_as_float(bv << 16);
-          const float y1 = (__uint_as_float(xv & 0xffff0000u) - mean) * rs * __uint_as_float(wv & 0xffff0000u) + __uint_as_float(bv & 0xffff0000u);
-          *reinterpret_cast<uint32_t*>(row + k) =
-              static_cast<uint32_t>(float_to_bf16_bits(y0)) | (static_cast<uint32_t>(float_to_bf16_bits(y1)) << 16);
-        }
+    } else {  // PRO_LAYERNORM
+      const float mean = sum * invK;
+      const float var = fmaxf(sq * invK - mean * mean, 0.f);
+      const float rs = rsqrtf(var + a.norm_eps);
+      for (int k = tid * 2; k < K; k += kGemvThreads * 2) {
+        const uint32_t xv = *reinterpret_cast<const uint32_t*>(row + k);
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(nw + k);
+        const uint32_t bv = *reinterpret_cast<const uint32_t*>(nb + k);
+        const float y0 = (__uint_as_float(xv << 16) - mean) * rs * __uint_as_float(wv << 16) + __uint_as_float(bv << 16);
+        const float y1 = (__uint_as_float(xv & 0xffff0000u) - mean) * rs * __uint_as_float(wv & 0xffff0000u) + __uint_as_float(bv & 0xffff0000u);
+        *reinterpret_cast<uint32_t*>(row + k) =
+            static_cast<uint32_t>(float_to_bf16_bits(y0)) | (static_cast<uint32_t>(float_to_bf16_bits(y1)) << 16);
       }
     }
   }
@@ -173,7 +152,7 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, float* 
 }
 
 // ------------------------------------------------------------------------------
-// epilogues: lane t (< T) finishes token t of the pair (y0 = row r0, y1 = row r1)
+// epilogues: one lane finishes token t of pair p (y0 = row r0, y1 = row r1)
 // ------------------------------------------------------------------------------
 template <int EPI>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
@@ -201,12 +180,20 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       q[0] = u0;
       q[half] = u1;
     } else if (pos >= 0 && pos < a.l_max) {
+      // in-place KV append (the fused form of kv_append_ref, reference.py:59-93):
+      // K rows are [Lmax][D], V is kept transposed [D][Lmax] (see attention.hip)
       const bool is_k = h < a.n_q_heads + a.n_kv_heads;
-      const int kvh = is_k ? h - a.n_q_heads : h - a.n_q_heads - a.n_kv_heads;
-      uint16_t* cache = static_cast<uint16_t*>(is_k ? a.k_cache : a.v_cache);
-      uint16_t* dst = cache + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max + pos) * D + i;
-      dst[0] = u0;
-      dst[half] = u1;
+      if (is_k) {
+        const int kvh = h - a.n_q_heads;
+        uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max + pos) * D + i;
+        dst[0] = u0;
+        dst[half] = u1;
+      } else {
+        const int kvh = h - a.n_q_heads - a.n_kv_heads;
+        uint16_t* dst = static_cast<uint16_t*>(a.v_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * D + i) * a.l_max + pos;
+        dst[0] = u0;
+        dst[static_cast<size_t>(half) * a.l_max] = u1;
+      }
     }
   } else if constexpr (EPI == EPI_RESID) {
     if (a.bias) {
@@ -252,146 +239,146 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
 
 // ------------------------------------------------------------------------------
 // main kernel
+//   MASK = false: every K slice is whole 32-element steps inside the row (all Llama
+//   production shapes); MASK = true: any K % 8 == 0 (lanes past K load nothing).
 // ------------------------------------------------------------------------------
-template <int TT, int EPI, int KSPLIT>
-__global__ __launch_bounds__(kGemvThreads) void gemv_pairs_kernel(const GemvArgs a) {
+template <int EPI, bool MASK>
+__global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = a.K, T = a.T;
+  const int KP = K + kXPad;
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + static_cast<size_t>(TT) * a.K * 2);  // [2][waves][2][TT]
+  // LDS: [x rows][partials 16 x 16x16 f32][norm sums / argmax fold]. When x alone nearly
+  // fills the CU's 160 KiB (T=5, K=14336) the partials alias the x rows (single-round
+  // launches only; one extra barrier before they are written).
+  const size_t xs_bytes = (static_cast<size_t>(T) * KP * 2 + 15) & ~static_cast<size_t>(15);
+  float* part = reinterpret_cast<float*>(a.alias_part ? smem : smem + xs_bytes);  // [16 waves][16][16]
+  float* red = reinterpret_cast<float*>(smem + xs_bytes + (a.alias_part ? 0 : sizeof(float) * kGemvWaves * 256));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int PPI = kGemvWaves / KSPLIT;  // pairs per workgroup iteration
-  const int sub = wave / KSPLIT;            // which pair of the iteration
-  const int kpart = wave % KSPLIT;          // which K slice
-  const int K = a.K, T = a.T;
-  // k-steps of 512 elements (64 lanes x 8) for this wave; K only has to be a
-  // multiple of 8: lanes past the end of the row are masked off
-  const int steps = (((K + 511) >> 9) + KSPLIT - 1) / KSPLIT;
-  const int kbase = kpart * steps * 512 + lane * 8;
+  const int g = lane >> 4, n = lane & 15;
+  const int ksplit = a.ksplit;                 // power of two, <= 16
+  const int tiles_per_round = kGemvWaves / ksplit;
+  const int kpart = wave & (ksplit - 1);
+  const int tslot = wave / ksplit;
+  const int kw = a.kw;                         // K span of one slice (multiple of 32)
+  const int k_begin = kpart * kw;
+  const int steps = kw >> 5;
   const uint16_t* W = static_cast<const uint16_t*>(a.W);
 
-  const int n_groups = (a.n_pairs + PPI - 1) / PPI;
-  const int n_iter = (n_groups - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
-  const int n_chunks = (steps + kChunk - 1) / kChunk;
-  const int total = n_iter * n_chunks;  // flattened (iteration, chunk) stream of this wave
+  // contiguous pair range of this workgroup, cut into n_tiles tiles of tile_pairs pairs
+  const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
+  const int p_hi = min(p_lo + a.ppw, a.n_pairs);
+  const int tile_pairs = a.tile_pairs;
+  const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;
+  const int rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
 
-  // one register buffer = kChunk k-steps x 2 rows
-  u32x4 bufA[2 * kChunk], bufB[2 * kChunk];
-
-  auto issue = [&](u32x4* buf, int idx) {
-    const int it = idx / n_chunks, c = idx - it * n_chunks;
-    const int p = (it * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x)) * PPI + sub;
-    if (p >= a.n_pairs) return;
+  // lane's weight row inside a tile: rows 0..7 = first rows of the pairs, 8..15 = second
+  // rows. Lanes without a pair alias the tile's first row (same address as lane 0: no
+  // extra traffic); their results are never read.
+  auto row_ptr = [&](int tile) -> const uint16_t* {
+    const int p0 = p_lo + tile * tile_pairs;
+    int p = p0 + (n & 7);
+    int second = n >> 3;
+    if ((n & 7) >= tile_pairs || p >= p_hi) { p = min(p0, p_hi - 1); second = 0; }
     int r0, r1;
     pair_rows<EPI>(a, p, r0, r1);
-    if (r1 >= a.N) r1 = r0;  // odd N (lm_head tail): read a valid row, result is dropped
-    const uint16_t* w0 = W + static_cast<size_t>(r0) * K + kbase;
-    const uint16_t* w1 = W + static_cast<size_t>(r1) * K + kbase;
+    int r = second ? r1 : r0;
+    if (r >= a.N) r = r0;  // odd N (vocabulary): second row of the last pair
+    return W + static_cast<size_t>(r) * K + k_begin + g * 8;
+  };
+
+  u32x4 buf[kBatch];
+  auto issue = [&](const uint16_t* wrow, int s0) {
 #pragma unroll
-    for (int j = 0; j < kChunk; ++j) {
-      const int s = c * kChunk + j;
-      if (s < steps && kbase + s * 512 < K) {
-        buf[2 * j + 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w0 + s * 512));
-        buf[2 * j + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w1 + s * 512));
-      }
+    for (int j = 0; j < kBatch; ++j) {
+      const int s = s0 + j;
+      bool ok = s < steps;  // wave-uniform
+      if constexpr (MASK) ok = ok && (k_begin + s * 32 + g * 8 + 8 <= K);
+      if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 32));
+      else buf[j] = u32x4{0u, 0u, 0u, 0u};
     }
   };
 
   // start the weight stream before x is staged: HBM latency hides under the prologue
-  if (total > 0) issue(bufA, 0);
+  const bool first_valid = tslot < n_tiles;
+  const uint16_t* wrow0 = row_ptr(first_valid ? tslot : 0);
+  if (first_valid) issue(wrow0, 0);
 
-  stage_x<TT>(a, xs, red);
-  __syncthreads();
+  stage_x(a, xs, KP, red);
 
-  float acc0[TT], acc1[TT];
-#pragma unroll
-  for (int t = 0; t < TT; ++t) { acc0[t] = 0.f; acc1[t] = 0.f; }
   float best_v = -INFINITY;
   int best_i = 0x7fffffff;
+  // token columns >= T read token T-1's row: their output columns are never used
+  const uint16_t* xrow = xs + static_cast<size_t>(n < T ? n : T - 1) * KP + k_begin + g * 8;
 
-  auto consume = [&](const u32x4* buf, int idx) {
-    const int it = idx / n_chunks, c = idx - it * n_chunks;
-    const int p = (it * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x)) * PPI + sub;
-    const bool valid = p < a.n_pairs;
-    if (valid) {
+  for (int r = 0; r < rounds; ++r) {
+    const int tile = r * tiles_per_round + tslot;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (tile < n_tiles) {
+      const uint16_t* wrow = (r == 0) ? wrow0 : row_ptr(tile);
+      for (int s0 = 0; s0 < steps; s0 += kBatch) {
+        if (r != 0 || s0 != 0) issue(wrow, s0);
 #pragma unroll
-      for (int j = 0; j < kChunk; ++j) {
-        const int s = c * kChunk + j;
-        if (s < steps && kbase + s * 512 < K) {
-          const uint16_t* xk = xs + kbase + s * 512;
-#pragma unroll
-          for (int t = 0; t < TT; ++t) {
-            if (t < T) {
-              const u32x4 xv = *reinterpret_cast<const u32x4*>(xk + static_cast<size_t>(t) * K);
-              acc0[t] = dot8(buf[2 * j + 0], xv, acc0[t]);
-              acc1[t] = dot8(buf[2 * j + 1], xv, acc1[t]);
+        for (int j = 0; j < kBatch; ++j) {
+          const int s = s0 + j;
+          if (s < steps) {
+            u32x4 xb;
+            if constexpr (MASK) {
+              const bool ok = (k_begin + s * 32 + g * 8 + 8 <= K);
+              xb = ok ? *reinterpret_cast<const u32x4*>(xrow + s * 32) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+              xb = *reinterpret_cast<const u32x4*>(xrow + s * 32);
             }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
+                                                          __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
           }
         }
       }
     }
-    if (c != n_chunks - 1) return;
-    // pair finished: wave reduce, (cross-wave reduce), epilogue
-    float my0 = 0.f, my1 = 0.f;
+    // publish this wave's partial 16x16 (row = 4g+reg, col = token n)
+    if (a.alias_part) __syncthreads();  // every wave is done reading x
+    float* slot = part + wave * 256;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      if (t < T) {
-        const float v0 = wave_reduce_sum(acc0[t]);
-        const float v1 = wave_reduce_sum(acc1[t]);
-        if (lane == t) { my0 = v0; my1 = v1; }
-      }
-      acc0[t] = 0.f;
-      acc1[t] = 0.f;
-    }
-    if constexpr (KSPLIT > 1) {
-      float* slot = red + (it & 1) * (kGemvWaves * 2 * TT);
-      if (lane < T) {
-        slot[(wave * 2 + 0) * TT + lane] = my0;
-        slot[(wave * 2 + 1) * TT + lane] = my1;
-      }
-      __syncthreads();  // uniform: every wave of the workgroup has the same trip count
-      if (kpart != 0) return;
-      if (lane < T) {
-#pragma unroll
-        for (int w = 1; w < KSPLIT; ++w) {
-          my0 += slot[((wave + w) * 2 + 0) * TT + lane];
-          my1 += slot[((wave + w) * 2 + 1) * TT + lane];
+    for (int q = 0; q < 4; ++q) slot[(4 * g + q) * 16 + n] = acc[q];
+    __syncthreads();
+    // epilogue items: thread -> (tile slot, pair, token); sums the ksplit slices
+    for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
+      const int ts = it >> 7, jp = (it >> 4) & 7, t = it & 15;  // t == tid & 15 on every trip
+      const int etile = r * tiles_per_round + ts;
+      const int p = p_lo + etile * tile_pairs + jp;
+      if (etile < n_tiles && jp < tile_pairs && p < p_hi && t < T) {
+        const float* base = part + (ts * ksplit) * 256;
+        float y0 = 0.f, y1 = 0.f;
+        for (int w = 0; w < ksplit; ++w) {
+          y0 += base[w * 256 + jp * 16 + t];
+          y1 += base[w * 256 + (jp + 8) * 16 + t];
         }
+        int r0, r1;
+        pair_rows<EPI>(a, p, r0, r1);
+        epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i);
       }
     }
-    if (valid && lane < T) {
-      int r0, r1;
-      pair_rows<EPI>(a, p, r0, r1);
-      epilogue<EPI>(a, p, r0, r1, lane, my0, my1, best_v, best_i);
-    }
-  };
-
-  for (int i = 0; i < total; i += 2) {
-    if (i + 1 < total) issue(bufB, i + 1);
-    consume(bufA, i);
-    if (i + 2 < total) issue(bufA, i + 2);
-    if (i + 1 < total) consume(bufB, i + 1);
+    if (r + 1 < rounds) __syncthreads();  // partial slots are rewritten next round
   }
 
   if constexpr (EPI == EPI_ARGMAX) {
-    // lane t of the leading waves holds token t's running best: fold the waves via LDS
+    // thread tid holds a running best for token tid & 15 (pairs (tid>>4)&7 of its tile
+    // slot): fold the 64 candidates per token through LDS
     __syncthreads();
-    float* sv = red;
-    int* si = reinterpret_cast<int*>(red + kGemvWaves * TT);
-    if (lane < T) {
-      sv[wave * TT + lane] = best_v;
-      si[wave * TT + lane] = best_i;
-    }
+    float* sv = part;                                  // [16 tokens][64]
+    int* si = reinterpret_cast<int*>(part + 16 * 64);
+    sv[(tid & 15) * 64 + (tid >> 4)] = best_v;
+    si[(tid & 15) * 64 + (tid >> 4)] = best_i;
     __syncthreads();
-    if (wave == 0 && lane < T) {
-#pragma unroll
-      for (int w = 1; w < kGemvWaves; ++w) {
-        const float ov = sv[w * TT + lane];
-        const int oi = si[w * TT + lane];
-        if (argmax_better(ov, oi, best_v, best_i)) { best_v = ov; best_i = oi; }
+    if (wave < T) {  // wave t folds token t
+      float bv = sv[wave * 64 + lane];
+      int bi = si[wave * 64 + lane];
+      wave_reduce_argmax(bv, bi);
+      if (lane == 0) {
+        a.part_val[static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bv;
+        a.part_idx[static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bi;
       }
-      a.part_val[static_cast<size_t>(lane) * gridDim.x + blockIdx.x] = best_v;
-      a.part_idx[static_cast<size_t>(lane) * gridDim.x + blockIdx.x] = best_i;
     }
   }
 }
@@ -399,89 +386,73 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_pairs_kernel(const GemvArgs
 // ------------------------------------------------------------------------------
 // host-side launch
 // ------------------------------------------------------------------------------
-static int pick_ksplit(int n_pairs, int K) {
-  // Give all 1024 waves (256 CUs x 4) the same number of (pair, K-slice) units.
-  const int steps = (K + 511) >> 9;
-  for (int ks : {1, 2, 4}) {
-    if (steps % ks) break;
-    const long units = static_cast<long>(n_pairs) * ks;
-    if (units >= 1024 && (units % 1024 == 0 || units >= 8 * 1024)) return ks;
-  }
-  int best = 1;
-  for (int ks : {1, 2, 4})
-    if (steps % ks == 0 && steps / ks >= 1) best = ks;
-  return (static_cast<long>(n_pairs) >= 4096) ? 1 : best;
+constexpr size_t kLdsLimit = 160 * 1024;
+static size_t gemv_smem(int T, int K, bool alias) {
+  const size_t xs = (static_cast<size_t>(T) * (K + kXPad) * 2 + 15) & ~static_cast<size_t>(15);
+  const size_t part = sizeof(float) * kGemvWaves * 256;
+  const size_t red = sizeof(float) * (kGemvMaxT * kGemvWaves * 2 + 64);
+  return (alias ? (xs > part ? xs : part) : xs + part) + red;
 }
 
-template <int TT, int EPI, int KS>
+// one workgroup (16 waves) per CU with an equal, contiguous share of the row pairs
+int gemv_grid(const GemvArgs& a, int* ppw_out) {
+  int grid = 256;
+  if (a.n_pairs < grid) grid = a.n_pairs;
+  const int ppw = (a.n_pairs + grid - 1) / grid;
+  grid = (a.n_pairs + ppw - 1) / ppw;
+  *ppw_out = ppw;
+  return grid;
+}
+
+template <int EPI, bool MASK>
 static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into once per kernel
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_pairs_kernel<TT, EPI, KS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemv_pairs_kernel<TT, EPI, KS>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK>), dim3(grid), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
-template <int TT, int EPI>
-static int launch_tt(const GemvArgs& a, int ksplit, int grid, size_t smem, hipStream_t st) {
-  switch (ksplit) {
-    case 1: return launch_one<TT, EPI, 1>(a, grid, smem, st);
-    case 2: return launch_one<TT, EPI, 2>(a, grid, smem, st);
-    default: return launch_one<TT, EPI, 4>(a, grid, smem, st);
-  }
-}
-
 template <int EPI>
-static int launch_epi(const GemvArgs& a, int tt, int ksplit, int grid, size_t smem, hipStream_t st) {
-  switch (tt) {
-    case 1: return launch_tt<1, EPI>(a, ksplit, grid, smem, st);
-    case 2: return launch_tt<2, EPI>(a, ksplit, grid, smem, st);
-    case 3: return launch_tt<3, EPI>(a, ksplit, grid, smem, st);
-    case 5: return launch_tt<5, EPI>(a, ksplit, grid, smem, st);
-    default: return launch_tt<9, EPI>(a, ksplit, grid, smem, st);
-  }
+static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
+  return mask ? launch_one<EPI, true>(a, grid, smem, st) : launch_one<EPI, false>(a, grid, smem, st);
 }
 
-int gemv_tile_for(int T) {
-  if (T <= 1) return 1;
-  if (T <= 2) return 2;
-  if (T <= 3) return 3;
-  if (T <= 5) return 5;
-  return 9;
-}
-
-int gemv_grid(const GemvArgs& a, int* ksplit_out) {
-  const int ks = pick_ksplit(a.n_pairs, a.K);
-  const int ppi = kGemvWaves / ks;
-  const int groups = (a.n_pairs + ppi - 1) / ppi;
-  int grid = groups < 256 ? groups : 256;
-  // big matrices (lm_head, gate/up): two workgroups per CU when LDS allows
-  const size_t smem = static_cast<size_t>(gemv_tile_for(a.T)) * a.K * 2 + 1024;
-  if (groups >= 2048 && smem <= 72 * 1024) grid = 512;
-  *ksplit_out = ks;
-  return grid;
-}
-
-int launch_gemv(const GemvArgs& a, int epi, hipStream_t st) {
+int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
+  GemvArgs a = a_in;
   SD_REQUIRE(a.T >= 1 && a.T <= kGemvMaxT, "gemv: T=%d out of range 1..%d", a.T, kGemvMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemv: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
   SD_REQUIRE(a.n_pairs > 0, "gemv: no rows");
-  const int tt = gemv_tile_for(a.T);
-  int ks = 1;
-  const int grid = gemv_grid(a, &ks);
-  const size_t smem = static_cast<size_t>(tt) * a.K * 2 + 1024;
-  SD_REQUIRE(smem <= 160 * 1024, "gemv: T=%d x K=%d does not fit LDS", a.T, a.K);
+  int ppw = 0;
+  const int grid = gemv_grid(a, &ppw);
+  a.ppw = ppw;
+  // tiles: a power-of-two count of <= 8-pair tiles; the 16 waves take (tile, K-slice) units
+  int n_tiles = 1;
+  while (n_tiles * kTilePairs < ppw) n_tiles <<= 1;
+  a.tile_pairs = (ppw + n_tiles - 1) / n_tiles;
+  int ksplit = kGemvWaves / (n_tiles < kGemvWaves ? n_tiles : kGemvWaves);
+  while (ksplit > 1 && (a.K + ksplit * 32 - 1) / (ksplit * 32) < 2) ksplit >>= 1;  // >= 2 steps per slice
+  a.ksplit = ksplit;
+  a.kw = ((a.K + ksplit * 32 - 1) / (ksplit * 32)) * 32;
+  const bool mask = (a.kw * ksplit != a.K);
+  size_t smem = gemv_smem(a.T, a.K, false);
+  a.alias_part = 0;
+  if (smem > kLdsLimit && n_tiles <= kGemvWaves / ksplit) {  // single round: partials may alias x
+    a.alias_part = 1;
+    smem = gemv_smem(a.T, a.K, true);
+  }
+  SD_REQUIRE(smem <= kLdsLimit, "gemv: T=%d x K=%d does not fit LDS", a.T, a.K);
   switch (epi) {
-    case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(a, tt, ks, grid, smem, st);
-    case EPI_RESID: return launch_epi<EPI_RESID>(a, tt, ks, grid, smem, st);
-    case EPI_SWIGLU: return launch_epi<EPI_SWIGLU>(a, tt, ks, grid, smem, st);
-    case EPI_GELU: return launch_epi<EPI_GELU>(a, tt, ks, grid, smem, st);
-    case EPI_ARGMAX: return launch_epi<EPI_ARGMAX>(a, tt, ks, grid, smem, st);
+    case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(a, mask, grid, smem, st);
+    case EPI_RESID: return launch_epi<EPI_RESID>(a, mask, grid, smem, st);
+    case EPI_SWIGLU: return launch_epi<EPI_SWIGLU>(a, mask, grid, smem, st);
+    case EPI_GELU: return launch_epi<EPI_GELU>(a, mask, grid, smem, st);
+    case EPI_ARGMAX: return launch_epi<EPI_ARGMAX>(a, mask, grid, smem, st);
     default: SD_REQUIRE(false, "gemv: unknown epilogue %d", epi);
   }
   return 0;

@@ -17,6 +17,11 @@ struct GemvArgs {
   const void* bias;  // bf16 [N] or null
   int N, K;
   int n_pairs;       // row pairs processed (see pair_rows)
+  int kw;            // K span per slice (set by launch_gemv)
+  int ppw;           // pairs per workgroup (set by launch_gemv)
+  int tile_pairs;    // pairs per tile, <= 8 (set by launch_gemv)
+  int ksplit;        // K slices per tile, power of two <= 16 (set by launch_gemv)
+  int alias_part;    // partial sums alias the staged x rows (set by launch_gemv)
   // activations in: bf16 [T][x_stride]
   const void* x;
   int x_stride;
@@ -46,8 +51,8 @@ struct GemvArgs {
   int* part_idx;
 };
 
-int gemv_tile_for(int T);
-int gemv_grid(const GemvArgs& a, int* ksplit_out);
+
+int gemv_grid(const GemvArgs& a, int* ppw_out);
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------

@@ -80,7 +80,7 @@ class HipModel:
         handle = _vp()
         _abi.check(self.lib.sd_model_create(ctypes.byref(mc), ctypes.byref(handle)), "sd_model_create")
         self.handle = handle
-        self.batch, self.l_max = int(batch), int(l_max)
+        self.batch, self.l_max = int(batch), (int(l_max) + 31) // 32 * 32  # whole 32-key blocks
         kv_bytes = self.lib.sd_model_kv_bytes(self.handle, self.batch, self.l_max)
         with torch.cuda.device(dev):
             # [n_layers][B][Hkv][Lmax][D] bf16 — sized for 288 GB of HBM: no paging, no realign copies
@@ -93,8 +93,9 @@ class HipModel:
 
     def kv_view(self):
         c = self.cfg
-        shape = (c.n_layers, self.batch, c.n_kv_heads, self.l_max, c.head_dim)
-        return self.k_cache.view(shape), self.v_cache.view(shape)
+        k_shape = (c.n_layers, self.batch, c.n_kv_heads, self.l_max, c.head_dim)
+        v_shape = (c.n_layers, self.batch, c.n_kv_heads, c.head_dim, self.l_max)  # V is kept transposed
+        return self.k_cache.view(k_shape), self.v_cache.view(v_shape)
 
     def forward(self, tokens: torch.Tensor, pos_base: torch.Tensor, pos_off: int = 0,
                 want_ids: bool = True, want_logits: bool = False, logits_dtype=torch.float32,
@@ -159,26 +160,34 @@ class HipSpecDec:
             _abi.check(self.lib.sd_specdec_create(draft.handle, target.handle, self.B, self.K, int(emit_mode),
                                                   ctypes.byref(handle)), "sd_specdec_create")
         self.handle = handle
+        # hipGraph capture is not allowed on the legacy default stream: the loop owns two
+        # non-default streams (verify/target and draft), ordered by events inside the step
+        with torch.cuda.device(self.device):
+            self.stream_t = torch.cuda.Stream(self.device)
+            self.stream_d = torch.cuda.Stream(self.device)
         self.rec_ints = self.lib.sd_specdec_record_ints(self.handle)
         ptr = self.lib.sd_specdec_record(self.handle)
         self._record = np.ctypeslib.as_array(ptr, shape=(self.B, self.rec_ints))
 
-    def set_row(self, b: int, seq_len: int, prev_tok: int, last_tok: int, active: bool = True,
-                stream: Optional[torch.cuda.Stream] = None):
+    def join_current_stream(self):
+        """Order the loop's streams after work already enqueued on torch's current
+        stream (prefill, weight uploads)."""
+        self.stream_t.wait_stream(torch.cuda.current_stream(self.device))
+
+    def set_row(self, b: int, seq_len: int, prev_tok: int, last_tok: int, active: bool = True):
         with torch.cuda.device(self.device):
             _abi.check(self.lib.sd_specdec_set_row(self.handle, b, int(seq_len), int(prev_tok), int(last_tok),
-                                                   1 if active else 0, _stream(stream, self.device)), "sd_specdec_set_row")
+                                                   1 if active else 0, self.stream_t.cuda_stream), "sd_specdec_set_row")
 
-    def step(self, stream_target: Optional[torch.cuda.Stream] = None,
-             stream_draft: Optional[torch.cuda.Stream] = None, use_graph: bool = True):
+    def step(self, use_graph: bool = True, two_streams: bool = True):
         with torch.cuda.device(self.device):
-            st = _stream(stream_target, self.device)
-            sd = stream_draft.cuda_stream if stream_draft is not None else None
-            _abi.check(self.lib.sd_specdec_step(self.handle, st, sd, 1 if use_graph else 0), "sd_specdec_step")
+            sd = self.stream_d.cuda_stream if two_streams else None
+            _abi.check(self.lib.sd_specdec_step(self.handle, self.stream_t.cuda_stream, sd,
+                                                1 if use_graph else 0), "sd_specdec_step")
 
-    def sync(self, stream: Optional[torch.cuda.Stream] = None) -> StepRecord:
+    def sync(self) -> StepRecord:
         with torch.cuda.device(self.device):
-            _abi.check(self.lib.sd_specdec_sync(self.handle, _stream(stream, self.device)), "sd_specdec_sync")
+            _abi.check(self.lib.sd_specdec_sync(self.handle, self.stream_t.cuda_stream), "sd_specdec_sync")
         return StepRecord(self._record, self.K)
 
     def close(self):

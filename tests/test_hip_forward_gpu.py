@@ -93,7 +93,7 @@ def test_verify_forward_logits_with_ragged_rows():
         if b:
             k, v = hm.kv_view()
             k[:, b, :, :n] = k[:, 0, :, :n]
-            v[:, b, :, :n] = v[:, 0, :, :n]
+            v[:, b, :, :, :n] = v[:, 0, :, :, :n]  # V cache is [.., D, Lmax]
     # redo row 0 last so that its cache row is its own
     toks0 = seqs[0][: lens[0]].to(torch.int32).view(1, -1).cuda()
     hm.forward(toks0, torch.zeros(1, dtype=torch.int32, device="cuda"), 0, skip_head=True)
