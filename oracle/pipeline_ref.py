@@ -1,0 +1,230 @@
+"""CPU restatement of the reference draft-then-verify loop.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates, for greedy decoding (`do_sample=False`, the SPECDEC_DETERMINISTIC setting of
+BASELINE.json):
+  * `SpeculativePipeline.generate_batch` — src/specdec/core/pipeline.py:1984-3733
+  * `SpeculativePipeline.generate`       — src/specdec/core/pipeline.py:984-1275
+  * `LongestPrefixPolicy.accept_tokens`  — src/specdec/policies/policies.py:156-180
+  * greedy `sample_bonus_token_from_logits` — pipeline.py:48-147 (argmax + clamp)
+on top of `oracle.model_ref.OracleLM` (the HF forward restated).
+
+Rows are treated independently: the reference right-pads mixed-length batches every
+step (sequence_utils.py:52-57) and its stream path takes the logits of the last —
+possibly padded — position (hf_wrappers.py:272-627), so rows shorter than the longest
+one are generated from a pad token. That is a defect of the reference's batching, not
+semantics; the per-row rules below are exactly what it applies to a batch of one and to
+the longest row of any batch (SURVEY §7 viii). Everything else, including the
+de-duplication heuristics that can drop or rewind tokens, is reproduced as written.
+
+`step_rules_batch` / `step_rules_single` are pure functions of (a, draft ids, target
+argmax ids, host state) so that the same restatement can check both a CPU run (ids
+from OracleLM) and a GPU run (ids from the HIP step record).
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .model_ref import OracleLM
+
+
+def longest_prefix(draft: Sequence[int], target_argmax: Sequence[int]) -> int:
+    """policies.py:156-180: first index where argmax(base_logits[i]) != proposed[i]."""
+    a = 0
+    for d, t in zip(draft, target_argmax):
+        if int(d) != int(t):
+            break
+        a += 1
+    return a
+
+
+@dataclass
+class RowState:
+    seq: List[int]                      # current_input_ids[i] (prompt + appended tokens)
+    generated: List[int] = field(default_factory=list)   # batch_generated_tokens[i]
+    active: bool = True
+    proposed: int = 0
+    accepted: int = 0
+    steps: int = 0
+
+
+def step_rules_batch(row: RowState, k: int, a: int, draft: Sequence[int], t: Sequence[int],
+                     max_tokens: int, eos: Optional[int], vocab: int) -> List[int]:
+    """One row of one generate_batch step. `t[i]` is the target's greedy token after the
+    row's sequence + draft[:i] (i = 0..k), which for i <= a is what the reference's
+    autoregressive base pass yields (base_tokens[i], and the extra forward for i == k).
+
+    Returns the tokens appended to the row's SEQUENCE (which the de-duplication can make
+    differ from what was appended to its generated list).
+    """
+    clamp = lambda x: max(0, min(int(x), vocab - 1))  # validate_and_clamp_tokens
+    gen = row.generated
+    if a > 0:
+        acc = [clamp(x) for x in t[:a]]                       # :3059-3075 accepted = base_tokens[:a]
+        if eos is not None and eos in acc:                    # :3120-3131 accepted EOS is cut
+            acc = acc[: acc.index(eos)]
+            row.active = False
+        # bonus: logits at position a (a < k, :3140-3163) or the extra forward over
+        # seq + acc (a == k, :3164-3231; acc possibly EOS-cut, so position len(acc))
+        bonus = clamp(t[a] if a < k else t[len(acc)])
+        if eos is not None and bonus == eos:                  # :3274-3280 bonus EOS is kept
+            row.active = False
+        acc = acc + [bonus]
+        if gen and acc:                                       # :3295-3318 overlap with generated tail
+            for c in range(min(5, len(gen), len(acc)), 0, -1):
+                if gen[-c:] == acc[:c]:
+                    acc = acc[c:]
+                    break
+        tokens_to_add = acc
+        gen.extend(tokens_to_add)                             # :3321-3322
+        accepted_len = len(tokens_to_add)
+        accepted_tokens = list(tokens_to_add)
+    else:
+        first = clamp(t[0])                                   # :3328-3345 first base token
+        accepted_tokens = [first]
+        if eos is not None and first == eos:                  # :3360-3365 EOS dropped, row stops
+            row.active = False
+            accepted_tokens = []
+        if accepted_tokens and gen and gen[-1] == accepted_tokens[0]:   # :3367-3376
+            accepted_tokens = []
+        if accepted_tokens:
+            gen.extend(accepted_tokens)
+        accepted_len = len(accepted_tokens)
+    row.proposed += k                                         # :3421-3424
+    row.accepted += accepted_len
+    appended: List[int] = []
+    if accepted_tokens:
+        acc = [clamp(x) for x in accepted_tokens]
+        cur = row.seq
+        if cur and acc:                                       # :3470-3530 overlap with sequence tail
+            c = min(5, len(cur), len(acc))
+            if c > 0 and cur[-c:] == acc[:c]:
+                if len(acc) > c:
+                    acc = acc[c:]
+                    if len(gen) >= c:
+                        del gen[-c:]
+                else:
+                    acc = []
+        appended = acc
+        row.seq = cur + acc
+    if len(gen) >= max_tokens:                                # :3589-3590
+        row.active = False
+    row.steps += 1
+    return appended
+
+
+def step_rules_single(row: RowState, k: int, a: int, draft: Sequence[int], t: Sequence[int],
+                      max_tokens: int, eos: Optional[int]) -> List[int]:
+    """One step of generate(): accepted tokens are the DRAFT ids cut to the remaining
+    budget (:1190-1206), a zero-accept step takes one base token (:1209-1225), no bonus."""
+    remaining = max_tokens - len(row.generated)
+    if a > 0:
+        new = [int(x) for x in draft[: min(a, max(remaining, 0))]]
+    else:
+        new = [int(t[0])] if remaining > 0 else []
+    row.proposed += k
+    row.accepted += a
+    row.generated.extend(new)
+    row.seq = row.seq + new
+    row.steps += 1
+    if len(row.generated) >= max_tokens:                      # :1258-1263
+        row.active = False
+    elif eos is not None and row.generated and row.generated[-1] == eos:   # :1266-1272
+        row.active = False
+    return new
+
+
+class OraclePipeline:
+    """The reference loop on CPU. `reprefill=True` re-feeds the whole prefix for every
+    one of the 2K forwards of a step, as the reference does with KV append off
+    (pipeline.py:1838; the configuration of every published Llama run) — that is the
+    `cpu_baseline` cost model; `reprefill=False` keeps per-model KV caches and gives the
+    same tokens faster (used by the parity tests)."""
+
+    def __init__(self, base: OracleLM, draft: OracleLM, k: int = 4, eos_token_id: Optional[int] = None,
+                 reprefill: bool = False):
+        self.base, self.draft, self.k = base, draft, int(k)
+        self.eos = eos_token_id
+        self.reprefill = reprefill
+        self.vocab = base.cfg.vocab
+        self.trace: List[Dict] = []
+
+    def _propose_and_verify(self, seq: List[int]):
+        """draft K greedy tokens from seq (pipeline.py:2397-2462) and the target's greedy
+        tokens t_0..t_K conditioned on seq + draft[:i]."""
+        k = self.k
+        ids = torch.tensor([seq], dtype=torch.int64)
+        d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill)
+        draft = d_ids[0].tolist()
+        if self.reprefill:
+            # reference-faithful cost: the base model generates K tokens autoregressively
+            # from the same prefix (speculative_scheduler.py:192-199), + the extra forward
+            # when everything was accepted (pipeline.py:3199-3206)
+            b_ids, _ = self.base.generate_tokens(ids, k, reprefill=True)
+            base = b_ids[0].tolist()
+            a = longest_prefix(draft, base)
+            t = list(base)
+            if a == k:
+                lg, _ = self.base.forward(torch.tensor([seq + base], dtype=torch.int64))
+                t.append(int(lg[0, -1].argmax()))
+            else:
+                t.append(-1)
+            # t[i] for i > a is not the target's token after draft[:i]; the rules only
+            # read t[:a+1]
+            return draft, t, a
+        # one cached pass over seq + draft: logits at the last K+1 positions
+        lg, _ = self.base.forward(torch.tensor([seq + draft], dtype=torch.int64))
+        t = lg[0, len(seq) - 1 :].argmax(-1).tolist()
+        a = longest_prefix(draft, t)
+        return draft, t, a
+
+    def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int) -> List[Dict]:
+        rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
+        self.trace = []
+        t0 = time.time()
+        step = 0
+        while step < max_tokens:                              # :1984 bound is STEPS, not tokens
+            step += 1
+            if not any(r.active for r in rows):
+                break
+            for i, r in enumerate(rows):
+                if not r.active:
+                    continue
+                draft, t, a = self._propose_and_verify(r.seq)
+                before = len(r.seq)
+                appended = step_rules_batch(r, self.k, a, draft, t, max_tokens, self.eos, self.vocab)
+                self.trace.append({"step": step, "row": i, "a": a, "draft": draft, "t": t[: a + 1],
+                                   "appended": appended, "seq_len": before})
+        dt = time.time() - t0
+        return [self._result(r, dt, len(rows), i) for i, r in enumerate(rows)]
+
+    def generate(self, prompt: Sequence[int], max_tokens: int) -> Dict:
+        r = RowState(seq=[int(x) for x in prompt])
+        self.trace = []
+        t0 = time.time()
+        step = 0
+        while len(r.generated) < max_tokens and step < 2 * max_tokens:   # :984-986
+            step += 1
+            draft, t, a = self._propose_and_verify(r.seq)
+            new = step_rules_single(r, self.k, a, draft, t, max_tokens, self.eos)
+            self.trace.append({"step": step, "a": a, "draft": draft, "t": t[: a + 1], "appended": new})
+            if not r.active:
+                break
+        return self._result(r, time.time() - t0, 1, 0)
+
+    @staticmethod
+    def _result(r: RowState, dt: float, batch: int, i: int) -> Dict:
+        n = len(r.generated)
+        return {
+            "generated_tokens": list(r.generated), "num_generated": n, "sequence": list(r.seq),
+            "proposed": r.proposed, "accepted": r.accepted, "steps": r.steps,
+            "acceptance_rate": r.accepted / max(r.proposed, 1),
+            "total_time_ms": dt * 1e3, "tokens_per_sec": n / dt if dt > 0 else 0.0,
+            "batch_index": i, "batch_size": batch,
+        }

@@ -112,3 +112,34 @@ def checksum(t: torch.Tensor) -> float:
     if x.dtype.is_floating_point:
         x = torch.nan_to_num(x.double(), nan=7.0, posinf=11.0, neginf=-13.0)
     return float(x.double().sum())
+
+
+# ---------------------------------------------------------------- G8 pipeline pairs
+def g8_pairs(dtype=torch.float32):
+    """The tiny Llama draft/target pairs of the pipeline goldens, rebuilt from seeds
+    (torch CPU generator; a weight checksum in the fixture guards against drift)."""
+    from specdec_hip import weights as W  # weight containers/builders only
+
+    rs = {"factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+          "original_max_position_embeddings": 64, "rope_type": "llama3"}
+    tcfg = W.ModelConfig(arch=W.ARCH_LLAMA, n_layers=2, d_model=64, n_heads=2, n_kv_heads=1, head_dim=32, d_ff=128,
+                         vocab=160, max_pos=256, rope_theta=500000.0, tie_embeddings=False, eos_token_id=2,
+                         rope_scaling=rs, name="g8-target")
+    dcfg = W.ModelConfig(arch=W.ARCH_LLAMA, n_layers=1, d_model=64, n_heads=2, n_kv_heads=1, head_dim=32, d_ff=128,
+                         vocab=160, max_pos=256, rope_theta=500000.0, tie_embeddings=False, eos_token_id=2,
+                         rope_scaling=rs, name="g8-draft")
+    out = {}
+    tgt = W.synthetic_llama(tcfg, seed=11, dtype=dtype, layer_gain=0.05, successor_mult=37, successor_add=5)
+    drf = W.synthetic_llama(dcfg, seed=12, dtype=dtype, layer_gain=0.05, successor_mult=37, successor_add=5,
+                            embed_from=tgt, flip_fraction=0.3)
+    out["structured"] = (drf, tgt)
+    # successor(t) = t: immediate repeats, the reference's de-duplication heuristics fire
+    tgt2 = W.synthetic_llama(tcfg, seed=21, dtype=dtype, layer_gain=0.05, successor_mult=1, successor_add=0)
+    drf2 = W.synthetic_llama(dcfg, seed=22, dtype=dtype, layer_gain=0.05, successor_mult=1, successor_add=0,
+                             embed_from=tgt2, flip_fraction=0.3)
+    out["repeating"] = (drf2, tgt2)
+    return out
+
+
+def weights_checksum(mw) -> float:
+    return float(sum(checksum(t) for name, t in mw.tensors() if not name.startswith("rope_")))

@@ -116,6 +116,98 @@ def gen_hf():
         print("hf golden:", name, tuple(logits.shape))
 
 
+def _save_local_hf_llama(mw, path):
+    """Write a ModelWeights (Llama layout) as a local HF checkpoint dir + a 1:1 tokenizer
+    ("t<i>" <-> id i), so the reference's HFWrapper can load it by PATH (hf_wrappers.py:87,115)."""
+    import transformers
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    c = mw.config
+    hcfg = transformers.LlamaConfig(
+        vocab_size=c.vocab, hidden_size=c.d_model, intermediate_size=c.d_ff, num_hidden_layers=c.n_layers,
+        num_attention_heads=c.n_heads, num_key_value_heads=c.n_kv_heads, head_dim=c.head_dim,
+        max_position_embeddings=c.max_pos, rms_norm_eps=c.norm_eps, rope_theta=c.rope_theta,
+        rope_scaling=c.rope_scaling, tie_word_embeddings=False, attention_bias=False, mlp_bias=False,
+        bos_token_id=1, eos_token_id=c.eos_token_id if c.eos_token_id is not None else 2, pad_token_id=0,
+    )
+    model = transformers.LlamaForCausalLM(hcfg)
+    sd = {"model.embed_tokens.weight": mw.tok_emb, "lm_head.weight": mw.lm_head, "model.norm.weight": mw.final_norm_w}
+    Hq, Hkv, D, ff = c.n_heads, c.n_kv_heads, c.head_dim, c.d_ff
+    for i, l in enumerate(mw.layers):
+        b = f"model.layers.{i}."
+        sd[b + "input_layernorm.weight"] = l.attn_norm_w
+        sd[b + "self_attn.q_proj.weight"] = l.wqkv[: Hq * D]
+        sd[b + "self_attn.k_proj.weight"] = l.wqkv[Hq * D : (Hq + Hkv) * D]
+        sd[b + "self_attn.v_proj.weight"] = l.wqkv[(Hq + Hkv) * D :]
+        sd[b + "self_attn.o_proj.weight"] = l.wo
+        sd[b + "post_attention_layernorm.weight"] = l.mlp_norm_w
+        sd[b + "mlp.gate_proj.weight"] = l.w_up[:ff]
+        sd[b + "mlp.up_proj.weight"] = l.w_up[ff:]
+        sd[b + "mlp.down_proj.weight"] = l.w_down
+    missing = model.load_state_dict({k: v.float().clone() for k, v in sd.items()}, strict=False)
+    assert not [m for m in missing.missing_keys if "rotary" not in m], missing
+    model.float().save_pretrained(path, safe_serialization=True)
+    vocab = {f"t{i:03d}": i for i in range(c.vocab)}  # fixed width: no special token is a prefix of another
+    tok = Tokenizer(models.WordLevel(vocab=vocab, unk_token="t000"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = transformers.PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="t000", pad_token="t000",
+                                                bos_token="t001", eos_token=f"t{hcfg.eos_token_id:03d}")
+    fast.save_pretrained(path)
+
+
+def gen_pipeline():
+    """G8: traces of the REFERENCE SpeculativePipeline on local tiny Llama pairs (CPU, fp32,
+    greedy, KV append off — the configuration of its published runs)."""
+    import shutil
+    import tempfile
+
+    pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "llm-inference-lab_amd")
+    sys.path.insert(0, pkg)
+    from specdec_hip import weights as W  # weight builders only (data), not the HIP path
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    from specdec import SpeculativePipeline  # the reference (REF/src on sys.path)
+
+    pairs = cases.g8_pairs(torch.float32)
+    tcfg = pairs["structured"][1].config
+
+    out = {}
+    arrays = {}
+    tmp = tempfile.mkdtemp(prefix="g8_")
+    try:
+        for pname, (d, t) in pairs.items():
+            ddir, tdir = os.path.join(tmp, pname + "_draft"), os.path.join(tmp, pname + "_target")
+            _save_local_hf_llama(d, ddir)
+            _save_local_hf_llama(t, tdir)
+            out[pname] = {"draft_checksum": cases.weights_checksum(d), "target_checksum": cases.weights_checksum(t),
+                          "runs": []}
+            rng = np.random.default_rng(5)
+            for k in (1, 2, 4):
+                pipe = SpeculativePipeline(base_model=tdir, draft_model=ddir, implementation="hf", device="cpu",
+                                           controller="fixed", controller_params={"k": k}, max_draft=k, seed=1234)
+                for max_tokens, plen in ((12, 6), (20, 9)):
+                    prompt_ids = rng.integers(4, tcfg.vocab, size=plen).tolist()
+                    prompt = " ".join(f"t{i:03d}" for i in prompt_ids)
+                    rb = pipe.generate_batch([prompt], max_tokens=max_tokens, temperature=0.7, do_sample=False)[0]
+                    rs = pipe.generate(prompt, max_tokens=max_tokens, temperature=0.7, do_sample=False)
+                    out[pname]["runs"].append({
+                        "k": k, "max_tokens": max_tokens, "prompt_ids": prompt_ids,
+                        "batch": {"generated_tokens": [int(x) for x in rb["generated_tokens"]],
+                                  "proposed": int(rb["proposed"]), "accepted": int(rb["accepted"]),
+                                  "steps": int(rb["batch_metrics"]["total_steps"])},
+                        "single": {"generated_tokens": [int(x) for x in rs["generated_tokens"]] if "generated_tokens" in rs else None,
+                                   "text": rs.get("text"), "proposed": int(rs["proposed"]), "accepted": int(rs["accepted"]),
+                                   "steps": int(rs["steps"])},
+                    })
+                    print(pname, "k", k, "batch", rb["generated_tokens"], "acc", rb["accepted"], "/", rb["proposed"],
+                          "| single", rs.get("text", "")[:60], rs["accepted"], "/", rs["proposed"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(HERE, "pipeline_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["kernels"]
@@ -123,3 +215,5 @@ if __name__ == "__main__":
         gen_kernels()
     if "hf" in which:
         gen_hf()
+    if "pipeline" in which:
+        gen_pipeline()
