@@ -205,9 +205,11 @@ int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax,
  *   ids_out  : optional device int32, argmax of token (b,m) at ids_out[b*ids_stride+m]
  *   logits_out: optional [B][M][vocab] (SD_BF16 | SD_F32)
  *   skip_head: 1 = only fill the cache (prefill of all but the last token)
+ *   row0, B  : the call works on rows [row0, row0+B) of the bound batch; element 0 of
+ *              tokens / pos_base / ids_out / logits_out belongs to row row0
  * B*M may exceed the 9 tokens one pass holds; the call then makes several passes. */
 int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride,
-                     const int32_t* pos_base, int pos_off, int B, int M,
+                     const int32_t* pos_base, int pos_off, int row0, int B, int M,
                      int32_t* ids_out, int ids_stride,
                      void* logits_out, int logits_dtype, int skip_head, void* stream);
 

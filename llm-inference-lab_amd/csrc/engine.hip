@@ -56,7 +56,7 @@ static size_t workspace_bytes(const sd_model_config& c) {
 
 // one pass: Bc rows x Mc tokens, Bc*Mc <= 9
 static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
-                        int pos_off, int b0, int Bc, int Mc, int32_t* ids_out, int ids_stride,
+                        int pos_off, int row0, int b0, int Bc, int Mc, int32_t* ids_out, int ids_stride,
                         void* logits_out, int logits_dtype, int logits_stride, int skip_head,
                         hipStream_t st) {
   const sd_model_config& c = m->cfg;
@@ -83,8 +83,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
   for (int l = 0; l < c.n_layers; ++l) {
     const sd_layer_weights& w = m->layers[l];
-    uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(b0) * Hkv * m->Lmax * D;
-    uint16_t* vc = m->v_cache + l * layer_kv + static_cast<size_t>(b0) * Hkv * m->Lmax * D;
+    uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
+    uint16_t* vc = m->v_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
 
     GemvArgs g{};
     g.T = T;
@@ -219,11 +219,13 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   return 0;
 }
 
+// rows [row0, row0+B) of the bound batch; tokens / pos_base / ids_out / logits_out are
+// indexed from row0 (element 0 of each array belongs to row row0)
 static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
-                         int pos_off, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
+                         int pos_off, int row0, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
                          int logits_dtype, int skip_head, hipStream_t st) {
   SD_REQUIRE(m && m->k_cache && m->x, "forward: model not bound (sd_model_bind)");
-  SD_REQUIRE(B >= 1 && B <= m->B, "forward: B=%d exceeds bound batch %d", B, m->B);
+  SD_REQUIRE(row0 >= 0 && B >= 1 && row0 + B <= m->B, "forward: rows [%d,%d) exceeds bound batch %d", row0, row0 + B, m->B);
   SD_REQUIRE(M >= 1, "forward: M=%d", M);
   SD_REQUIRE(tokens && pos_base, "forward: NULL tokens/pos_base");
   const int esz = (logits_dtype == SD_F32) ? 4 : 2;
@@ -234,7 +236,7 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? B - b0 : Bc;
       void* lo = logits_out ? static_cast<char*>(logits_out) + static_cast<size_t>(b0) * M * V * esz : nullptr;
-      if (int rc = forward_pass(m, tokens, tok_stride, pos_base, pos_off, b0, nb, M, ids_out, ids_stride, lo,
+      if (int rc = forward_pass(m, tokens, tok_stride, pos_base, pos_off, row0, b0, nb, M, ids_out, ids_stride, lo,
                                 logits_dtype, V, skip_head, st))
         return rc;
     }
@@ -245,7 +247,7 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
     for (int m0 = 0; m0 < M; m0 += kGemvMaxT) {
       const int mc = (M - m0 < kGemvMaxT) ? M - m0 : kGemvMaxT;
       void* lo = logits_out ? static_cast<char*>(logits_out) + (static_cast<size_t>(b0) * M + m0) * V * esz : nullptr;
-      if (int rc = forward_pass(m, tokens + m0, tok_stride, pos_base, pos_off + m0, b0, 1, mc,
+      if (int rc = forward_pass(m, tokens + m0, tok_stride, pos_base, pos_off + m0, row0, b0, 1, mc,
                                 ids_out ? ids_out + m0 : nullptr, ids_stride, lo, logits_dtype, V, skip_head, st))
         return rc;
     }
@@ -330,10 +332,10 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
 }
 
 extern "C" int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
-                                int pos_off, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
+                                int pos_off, int row0, int B, int M, int32_t* ids_out, int ids_stride, void* logits_out,
                                 int logits_dtype, int skip_head, void* stream) {
   clear_error();
-  return model_forward(m, tokens, tok_stride, pos_base, pos_off, B, M, ids_out, ids_stride, logits_out,
+  return model_forward(m, tokens, tok_stride, pos_base, pos_off, row0, B, M, ids_out, ids_stride, logits_out,
                        logits_dtype, skip_head, static_cast<hipStream_t>(stream));
 }
 
@@ -385,7 +387,7 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     const int M = (i == 0) ? 2 : 1;
     const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
     const int off = (i == 0) ? -1 : i;
-    if (int rc = model_forward(s->draft, toks, M, s->st.cur_len, off, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d))
+    if (int rc = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d))
       return rc;
     if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
   }
@@ -394,7 +396,7 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     SD_HIP_CHECK(hipStreamWaitEvent(st_t, s->ev_join, 0));
   }
   // verify: one forward over (last, d_1..d_K)
-  if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, B, K + 1, s->st.target_ids,
+  if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, K + 1, s->st.target_ids,
                              K + 1, nullptr, SD_BF16, 0, st_t))
     return rc;
   if (int rc = launch_accept(s->st, s->mode, st_t)) return rc;

@@ -64,7 +64,7 @@ SIGNATURES = {
     "sd_model_bind": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_size]),
     "sd_model_forward": (
         _c_int,
-        [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+        [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
          _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     ),
     "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),

@@ -54,6 +54,8 @@ class HipModel:
         self.lib = _abi.load()
         self.cfg: ModelConfig = weights.config
         dev = torch.device(device) if device is not None else weights.tok_emb.device
+        if dev.type == "cuda" and dev.index is None:
+            dev = weights.tok_emb.device if weights.tok_emb.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
         if dev.type != "cuda":
             raise RuntimeError("HipModel needs weights on a GPU (PyTorch-ROCm device 'cuda'); there is no CPU path")
         self.device = dev
@@ -99,8 +101,9 @@ class HipModel:
 
     def forward(self, tokens: torch.Tensor, pos_base: torch.Tensor, pos_off: int = 0,
                 want_ids: bool = True, want_logits: bool = False, logits_dtype=torch.float32,
-                skip_head: bool = False, stream: Optional[torch.cuda.Stream] = None):
-        """tokens int32 [B][M] on the device, pos_base int32 [B]. Appends to the cache in place."""
+                skip_head: bool = False, stream: Optional[torch.cuda.Stream] = None, row0: int = 0):
+        """tokens int32 [B][M] on the device, pos_base int32 [B] for rows [row0, row0+B) of the
+        bound batch. Appends to the cache in place."""
         assert tokens.dtype == torch.int32 and tokens.dim() == 2 and tokens.device == self.device
         assert pos_base.dtype == torch.int32 and pos_base.shape == (tokens.shape[0],) and pos_base.device == self.device
         B, M = tokens.shape
@@ -111,7 +114,7 @@ class HipModel:
             logits = torch.empty((B, M, self.cfg.vocab), dtype=logits_dtype, device=self.device)
         with torch.cuda.device(self.device):
             rc = self.lib.sd_model_forward(
-                self.handle, tokens.data_ptr(), M, pos_base.data_ptr(), int(pos_off), B, M,
+                self.handle, tokens.data_ptr(), M, pos_base.data_ptr(), int(pos_off), int(row0), B, M,
                 _ptr(ids), M, _ptr(logits),
                 _abi.SD_F32 if logits_dtype == torch.float32 else _abi.SD_BF16,
                 1 if skip_head else 0, _stream(stream, self.device))

@@ -1,0 +1,403 @@
+"""`SpeculativePipeline` — the draft-then-verify loop on MI355X.
+
+Public surface of the reference (src/specdec/core/pipeline.py): the constructor
+arguments (:198-218), `generate(prompt, max_tokens, temperature, do_sample)` (:893) and
+`generate_batch(prompts, ...)` (:1605), and the result-dict keys (:1350-1380, :3876-3905).
+
+What runs underneath is different. The reference makes 2K HF forwards per step over the
+whole prefix from Python, synchronising the host several times per row. Here one call
+per step (`HipSpecDec.step`) replays a hipGraph that holds the K draft forwards, ONE
+K+1-token verify forward of the target over its appended KV cache, the accept scan and
+the in-place state advance; the host reads one small pinned record per step and applies
+the reference's host-side rules to it (EOS cut, bonus, de-duplication, budget — restated
+in `_rules_batch` / `_rules_single`). When those rules leave a row where the device
+assumed (the common case) nothing else happens; when they do not (a de-duplication
+dropped or rewound tokens), the row's caches are rebuilt from its sequence.
+
+Greedy decoding (`do_sample=False`) is the device-resident path. Sampling is not on it
+yet and is refused loudly rather than served from a slower substitute.
+"""
+
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import psutil
+import torch
+import yaml
+
+from specdec_hip.engine import HipModel, HipSpecDec
+
+from ..models.hip_lm import HipLM, create_hip_lm
+from ..policies.controllers import create_controller
+from ..policies.policies import create_policy
+from ..utils.deterministic import ensure_deterministic, set_deterministic_mode
+from ..utils.interfaces import LanguageModel
+
+PromptLike = Union[str, Sequence[int], torch.Tensor]
+
+_DEFAULTS: Dict[str, Any] = {
+    "base_model": "synthetic:llama-3.2-3b",
+    "draft_model": "synthetic:llama-3.2-1b",
+    "max_draft": 4,
+    "implementation": "hip",
+    "temperature": 0.7,
+    "do_sample": False,
+    "max_new_tokens": 64,
+    "top_p": 0.9,
+    "top_k": 50,
+    "repetition_penalty": 1.0,
+    "device": "cuda",
+    "seed": 1234,
+    "log_level": "INFO",
+    "verbose": False,
+    "draft_mode": "vanilla",
+}
+
+
+def _clamp(tok: int, vocab: int) -> int:
+    return 0 if tok < 0 else (vocab - 1 if tok >= vocab else int(tok))
+
+
+class _Row:
+    __slots__ = ("seq", "generated", "active", "proposed", "accepted")
+
+    def __init__(self, seq: List[int]):
+        self.seq, self.generated, self.active = seq, [], True
+        self.proposed = self.accepted = 0
+
+
+class SpeculativePipeline:
+    def __init__(self, base_lm: Optional[LanguageModel] = None, draft_lm: Optional[LanguageModel] = None,
+                 config_path: Optional[str] = None, base_model: Optional[Any] = None,
+                 draft_model: Optional[Any] = None, max_draft: Optional[int] = None, device: str = "auto",
+                 seed: Optional[int] = None, implementation: Optional[str] = None,
+                 force_device: Optional[str] = None, policy: str = "longest_prefix",
+                 policy_params: Optional[Dict[str, Any]] = None, controller: str = "fixed",
+                 controller_params: Optional[Dict[str, Any]] = None, draft_mode: str = "vanilla",
+                 enable_optimization: bool = True, enable_profiling: bool = False,
+                 profile_dir: Optional[str] = None):
+        self.logger = logging.getLogger(__name__)
+        self.config = self._load_config(config_path)
+        for key, val in (("base_model", base_model), ("draft_model", draft_model), ("max_draft", max_draft),
+                         ("seed", seed), ("implementation", implementation), ("draft_mode", draft_mode)):
+            if val is not None:
+                self.config[key] = val
+        impl = self.config["implementation"]
+        if impl not in ("hip", "hf"):
+            # "fake" (FakeLM test double) and CPU/MPS implementations of the reference have no
+            # counterpart here: the product is the GPU path
+            raise ValueError(f"implementation={impl!r} is not available in this build (use 'hip')")
+        if draft_mode != "vanilla":
+            raise NotImplementedError(f"draft_mode={draft_mode!r}: only 'vanilla' drafting is on the HIP path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("SpeculativePipeline needs a GPU (PyTorch-ROCm device 'cuda'); there is no CPU path")
+        self.device = "cuda"
+        self.dtype = torch.bfloat16
+        self.amp_enabled = False
+        self.enable_cuda_graph = True  # hipGraph replay of the step (the reference pins this to False)
+        if self.config.get("seed") is not None:
+            set_deterministic_mode(int(self.config["seed"]))
+        ensure_deterministic(int(self.config.get("seed") or 1234))
+
+        self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
+        self.draft_lm = draft_lm if draft_lm is not None else create_hip_lm(self.config["draft_model"])
+        for who, lm in (("base", self.base_lm), ("draft", self.draft_lm)):
+            if not isinstance(lm, HipLM):
+                raise TypeError(f"{who}_lm must be a HipLM (got {type(lm).__name__}): the step loop drives the "
+                                "models through the C-ABI engine, not through generate_tokens")
+        if self.base_lm.vocab_size != self.draft_lm.vocab_size:
+            raise ValueError(f"draft/base vocabularies differ: {self.draft_lm.vocab_size} vs {self.base_lm.vocab_size}")
+        self.speculative_enabled = True
+        self.policy = create_policy(policy, **(policy_params or {}))
+        if policy != "longest_prefix":
+            raise NotImplementedError("only the longest_prefix policy runs inside the device step; the other "
+                                      "policies are available through policies.create_policy for host use")
+        self.controller = create_controller(controller, **(controller_params or {}))
+        from src.scheduler import create_speculative_scheduler
+
+        self.scheduler = create_speculative_scheduler(device="cuda")
+        self.metrics: Dict[str, Any] = {}
+        self._runtimes: Dict[Any, Any] = {}
+
+    # ------------------------------------------------------------------ configuration
+    def _load_config(self, config_path: Optional[str]) -> Dict[str, Any]:
+        """Flat YAML merged over the defaults (pipeline.py:398-438)."""
+        cfg = dict(_DEFAULTS)
+        if config_path:
+            with open(config_path) as f:
+                loaded = yaml.safe_load(f) or {}
+            if not isinstance(loaded, dict):
+                raise ValueError(f"{config_path}: expected a flat mapping")
+            cfg.update(loaded)
+        return cfg
+
+    # ------------------------------------------------------------------ runtime pieces
+    def _runtime(self, batch: int, need_len: int, k: int, emit_mode: int):
+        """Engine instances (own KV caches over the shared weights) + the step loop object."""
+        key = (batch, emit_mode)
+        rt = self._runtimes.get(key)
+        if rt is None or rt["l_max"] < need_len:
+            l_max = (max(need_len, 256) + 63) // 64 * 64
+            rt = {"l_max": l_max, "target": self.base_lm.new_engine(batch, l_max),
+                  "draft": self.draft_lm.new_engine(batch, l_max), "loops": {}}
+            self._runtimes[key] = rt
+        loop = rt["loops"].get(k)
+        if loop is None:
+            loop = rt["loops"][k] = HipSpecDec(rt["draft"], rt["target"], batch, k, emit_mode)
+        return rt, loop
+
+    def _encode(self, prompt: PromptLike) -> List[int]:
+        if isinstance(prompt, str):
+            return [int(x) for x in self.base_lm.encode(prompt).flatten().tolist()]
+        if isinstance(prompt, torch.Tensor):
+            return [int(x) for x in prompt.flatten().tolist()]
+        return [int(x) for x in prompt]
+
+    def _prefill_row(self, rt, b: int, seq: List[int]) -> None:
+        """KV of seq[:-1] into row b of both caches (the step recomputes the last two)."""
+        if len(seq) < 2:
+            return
+        toks = torch.tensor([seq[:-1]], dtype=torch.int32, device="cuda")
+        zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+        rt["target"].forward(toks, zero, 0, skip_head=True, row0=b)
+        rt["draft"].forward(toks, zero, 0, skip_head=True, row0=b)
+
+    def _prefill(self, rt, rows: List[_Row]) -> None:
+        lens = {len(r.seq) for r in rows}
+        if len(lens) == 1 and len(rows[0].seq) >= 2:
+            toks = torch.tensor([r.seq[:-1] for r in rows], dtype=torch.int32, device="cuda")
+            zero = torch.zeros(len(rows), dtype=torch.int32, device="cuda")
+            rt["target"].forward(toks, zero, 0, skip_head=True)
+            rt["draft"].forward(toks, zero, 0, skip_head=True)
+        else:
+            for b, r in enumerate(rows):
+                self._prefill_row(rt, b, r.seq)
+
+    @staticmethod
+    def _set_row(loop: HipSpecDec, b: int, row: _Row) -> None:
+        seq = row.seq
+        loop.set_row(b, len(seq), seq[-2] if len(seq) >= 2 else 0, seq[-1], row.active)
+
+    # ------------------------------------------------------------------ host-side rules
+    def _rules_batch(self, row: _Row, k: int, a: int, t: List[int], max_tokens: int, eos: Optional[int]) -> None:
+        """One row of one generate_batch step (pipeline.py:3018-3590), from the step record:
+        a = accepted length, t[i] = target argmax after the row's sequence + d_1..d_i."""
+        V = self.base_lm.vocab_size
+        gen = row.generated
+        if a > 0:
+            acc = [_clamp(x, V) for x in t[:a]]
+            if eos is not None and eos in acc:           # accepted EOS: cut there, row stops (:3120-3131)
+                acc = acc[: acc.index(eos)]
+                row.active = False
+            bonus = _clamp(t[a] if a < k else t[len(acc)], V)   # (:3140-3231)
+            if eos is not None and bonus == eos:         # bonus EOS stays in the output (:3274-3280)
+                row.active = False
+            acc.append(bonus)
+            if gen:                                      # overlap with the generated tail (:3295-3318)
+                for c in range(min(5, len(gen), len(acc)), 0, -1):
+                    if gen[-c:] == acc[:c]:
+                        acc = acc[c:]
+                        break
+            gen.extend(acc)
+            emitted = acc
+        else:
+            emitted = [_clamp(t[0], V)]
+            if eos is not None and emitted[0] == eos:    # (:3360-3365)
+                row.active = False
+                emitted = []
+            if emitted and gen and gen[-1] == emitted[0]:  # (:3367-3376)
+                emitted = []
+            gen.extend(emitted)
+        row.proposed += k
+        row.accepted += len(emitted)
+        if emitted:                                      # sequence update with its own overlap rule (:3470-3572)
+            acc, cur = list(emitted), row.seq
+            c = min(5, len(cur), len(acc))
+            if c > 0 and cur[-c:] == acc[:c]:
+                if len(acc) > c:
+                    acc = acc[c:]
+                    if len(gen) >= c:
+                        del gen[-c:]
+                else:
+                    acc = []
+            row.seq = cur + acc
+        if len(gen) >= max_tokens:                       # (:3589-3590)
+            row.active = False
+
+    @staticmethod
+    def _rules_single(row: _Row, k: int, a: int, d: List[int], t: List[int], max_tokens: int,
+                      eos: Optional[int]) -> None:
+        """One step of generate() (pipeline.py:1190-1272): draft ids cut to the budget, or one
+        base token when nothing was accepted."""
+        remaining = max_tokens - len(row.generated)
+        new = [int(x) for x in d[: min(a, max(remaining, 0))]] if a > 0 else ([int(t[0])] if remaining > 0 else [])
+        row.proposed += k
+        row.accepted += a
+        row.generated.extend(new)
+        row.seq = row.seq + new
+        if len(row.generated) >= max_tokens:
+            row.active = False
+        elif eos is not None and row.generated and row.generated[-1] == eos:
+            row.active = False
+
+    # ------------------------------------------------------------------ the loop
+    def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int):
+        B = len(prompts)
+        rows = [_Row(list(p)) for p in prompts]
+        for r in rows:
+            if not r.seq:
+                raise ValueError("empty prompt")
+        eos = self.base_lm.get_tokenizer_info().get("eos_token_id")
+        k_max = getattr(self.controller, "max_k", None) or getattr(self.controller, "k", 4)
+        need = max(len(r.seq) for r in rows) + max_tokens + 2 * int(k_max) + 8
+        t_start = time.time()
+        k = int(self.controller.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
+        rt, loop = self._runtime(B, need, k, emit_mode)
+        self._prefill(rt, rows)
+        loop.join_current_stream()
+        for b, r in enumerate(rows):
+            self._set_row(loop, b, r)
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0}
+        step = 0
+        while step < step_limit and any(r.active for r in rows):
+            step += 1
+            if step > 1:
+                ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
+                       "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+                k_new = int(self.controller.get_k(step, ctx))
+                if k_new <= 0:
+                    break
+                if k_new != k:  # adaptive K: another captured step over the same caches
+                    loop.sync()
+                    k = k_new
+                    rt, loop = self._runtime(B, need, k, emit_mode)
+                    loop.join_current_stream()
+                    for b, r in enumerate(rows):
+                        self._set_row(loop, b, r)
+            t0 = time.time()
+            loop.step(use_graph=True)
+            rec = loop.sync()
+            stats["device_ms"] += (time.time() - t0) * 1e3
+            for b, r in enumerate(rows):
+                if not r.active:
+                    continue
+                a = int(rec.accept_len[b])
+                t = [int(x) for x in rec.target_ids[b]]
+                d = [int(x) for x in rec.draft_tokens[b]]
+                before, acc0 = r.seq, r.accepted
+                n_new = int(rec.n_new[b])
+                assumed = before + t[:n_new]  # what the device advanced to
+                if emit_mode == HipSpecDec.EMIT_BONUS:
+                    self._rules_batch(r, k, a, t, max_tokens, eos)
+                else:
+                    self._rules_single(r, k, a, d, t, max_tokens, eos)
+                stats["proposed"] += k
+                stats["accepted"] += r.accepted - acc0
+                if not r.active:
+                    self._set_row(loop, b, r)       # freeze the row on the device
+                elif r.seq != assumed:
+                    stats["resyncs"] += 1           # the host rules rewrote the row: rebuild its caches
+                    loop.sync()
+                    self._prefill_row(rt, b, r.seq)
+                    loop.join_current_stream()
+                    self._set_row(loop, b, r)
+                if len(r.seq) + 2 * k + 4 > rt["l_max"]:
+                    r.active = False
+                    self._set_row(loop, b, r)
+            stats["steps"] = step
+        torch.cuda.synchronize()
+        stats["total_ms"] = (time.time() - t_start) * 1e3
+        stats["k"] = k
+        return rows, stats
+
+    # ------------------------------------------------------------------ public API
+    def _check_sampling(self, do_sample: bool) -> None:
+        if do_sample:
+            raise NotImplementedError(
+                "do_sample=True: sampled decoding is not on the HIP path yet (DESIGN.md, 'next'); "
+                "call with do_sample=False (greedy, the SPECDEC_DETERMINISTIC configuration)")
+
+    def generate(self, prompt: PromptLike, max_tokens: Optional[int] = None, temperature: Optional[float] = None,
+                 do_sample: Optional[bool] = None, **kwargs) -> Dict[str, Any]:
+        """Single-prompt speculative decoding (reference :893-1413): accepted tokens are the
+        draft's, no bonus token, a zero-accept step emits one base token."""
+        t_begin = time.time()
+        max_tokens = max_tokens or self.config["max_new_tokens"]
+        temperature = temperature or self.config["temperature"]
+        do_sample = do_sample if do_sample is not None else self.config["do_sample"]
+        self._check_sampling(do_sample)
+        ids = self._encode(prompt)
+        rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens)
+        r = rows[0]
+        total_ms = (time.time() - t_begin) * 1e3
+        self.metrics = {"total_proposed": r.proposed, "total_accepted": r.accepted, "total_steps": st["steps"],
+                        "total_verification_time_ms": st["device_ms"], "total_generation_time_ms": total_ms,
+                        "kv_appended_tokens_total": len(r.generated), "kv_append_time_ms": 0.0}
+        text = self.base_lm.decode(r.generated) if r.generated else ""
+        n = len(r.generated)
+        return {
+            "text": text, "generated_tokens": list(r.generated), "latency_ms": total_ms,
+            "proposed": r.proposed, "accepted": r.accepted,
+            "acceptance_rate": r.accepted / r.proposed if r.proposed > 0 else 0.0,
+            "tokens_per_sec": n / (total_ms / 1e3) if total_ms > 0 else 0.0, "steps": st["steps"],
+            "verification_time_ms": st["device_ms"], "generation_time_ms": total_ms,
+            "kv_appended_tokens_total": n, "kv_append_time_ms": 0.0, "kv_append_enabled": True,
+            "kv_append_backend": "hip", **self._sysinfo(),
+        }
+
+    def generate_batch(self, prompts: Sequence[PromptLike], max_tokens: Optional[int] = None,
+                       temperature: Optional[float] = None, do_sample: Optional[bool] = None,
+                       **kwargs) -> List[Dict[str, Any]]:
+        """Batched speculative decoding (reference :1605-3931): base tokens + bonus token per
+        step, step-count bound, no truncation to max_tokens. Rows are independent sequences."""
+        if not prompts:
+            return []
+        max_tokens = max_tokens or self.config["max_new_tokens"]
+        temperature = temperature or self.config["temperature"]
+        do_sample = do_sample if do_sample is not None else self.config["do_sample"]
+        self._check_sampling(do_sample)
+        ids = [self._encode(p) for p in prompts]
+        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens)
+        total_ms = st["total_ms"]
+        tot_prop = sum(r.proposed for r in rows)
+        tot_acc = sum(r.accepted for r in rows)
+        tot_gen = sum(len(r.generated) for r in rows)
+        batch_metrics = {
+            "total_proposed": tot_prop, "total_accepted": tot_acc, "total_generated_tokens": tot_acc,
+            "total_steps": st["steps"], "total_draft_time_ms": 0.0, "total_verification_time_ms": st["device_ms"],
+            "total_generation_time_ms": total_ms, "total_time_ms": total_ms,
+            "tokens_per_sec": tot_acc / (total_ms / 1e3) if total_ms > 0 else 0.0,
+            "emitted_tokens": tot_gen, "resyncs": st["resyncs"], "k": st["k"],
+        }
+        out = []
+        for i, (p, r) in enumerate(zip(prompts, rows)):
+            n = len(r.generated)
+            text = self.base_lm.decode(r.generated) if r.generated else ""
+            tps = n / (total_ms / 1e3) if total_ms > 0 else 0.0
+            out.append({
+                "prompt": p, "text": text, "generated_text": text, "generated_tokens": list(r.generated),
+                "num_generated": n, "batch_index": i, "batch_size": len(rows),
+                "latency_ms": total_ms / n if n else 0.0, "total_time_ms": total_ms,
+                "tokens_per_sec": tps, "throughput_tokens_per_sec": tps,
+                "acceptance_rate": tot_acc / max(tot_prop, 1),   # batch-wide, as the reference (:3834)
+                "proposed": r.proposed, "accepted": r.accepted,
+                "draft_avg_ms": 0.0, "verify_avg_ms": st["device_ms"] / max(st["steps"], 1),
+                "batch_metrics": batch_metrics, "kv_append_enabled": True, "kv_append_backend": "hip",
+                "kv_appended_tokens": n, "kv_append_time_ms": 0.0, "sequence": list(r.seq),
+            })
+        return out
+
+    def _sysinfo(self) -> Dict[str, Any]:
+        return {
+            "mem_rss_mb": psutil.Process().memory_info().rss / 1024 / 1024,
+            "cuda_mem_allocated_mb": float(torch.cuda.memory_allocated() / 1024 / 1024),
+            "cuda_mem_peak_mb": float(torch.cuda.max_memory_allocated() / 1024 / 1024),
+            "policy": self.policy.get_info(), "controller": self.controller.get_info(),
+            "impl": "hip", "device": self.device, "dtype": "bfloat16", "amp_enabled": False,
+            "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name,
+            "draft_mode": self.config.get("draft_mode", "vanilla"),
+        }

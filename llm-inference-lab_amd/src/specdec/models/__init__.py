@@ -1,0 +1,2 @@
+"""Model wrappers (reference: src/specdec/models/)."""
+from .hip_lm import HipLM, IdTokenizer, create_hip_lm  # noqa: F401

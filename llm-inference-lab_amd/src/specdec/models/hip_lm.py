@@ -1,0 +1,223 @@
+"""`HipLM` — the `LanguageModel` wrapper over the gfx950 decoder forward.
+
+It stands where the reference has `HFWrapper` (src/specdec/models/hf_wrappers.py:20-1079):
+same interface (`generate_tokens`, `encode`/`decode`, `get_tokenizer_info`, the KV hooks),
+but the forward is the C-ABI library (csrc/), the KV cache is a preallocated device buffer
+appended to in place by the forward itself, and weights come from a local checkpoint
+directory or a synthetic initialiser — nothing is fetched by name.
+
+`generate_tokens` keeps the reference contract (k greedy tokens + their logits, one
+forward per token after the prefix has been cached). The pipeline's fast path does not
+go through it: it drives both models with `specdec_hip.engine.HipSpecDec`, one graph
+launch per step."""
+
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from specdec_hip import weights as W
+from specdec_hip.engine import HipModel
+
+from ..cache.kv_types import KVCache
+from ..utils.interfaces import LanguageModel
+from ..utils.token_validation import validate_and_clamp_tokens
+
+logger = logging.getLogger(__name__)
+
+
+class IdTokenizer:
+    """Whitespace-separated decimal token ids: the tokenizer of synthetic runs."""
+
+    def __init__(self, vocab_size: int, eos_token_id: Optional[int] = None, pad_token_id: int = 0):
+        self.vocab_size = vocab_size
+        self.eos_token_id = eos_token_id if eos_token_id is not None else vocab_size - 1
+        self.pad_token_id = pad_token_id
+        self.bos_token_id = None
+
+    def encode(self, text: str) -> List[int]:
+        return [int(t) for t in text.split()]
+
+    def decode(self, ids, skip_special_tokens: bool = True) -> str:
+        return " ".join(str(int(i)) for i in ids)
+
+    def __call__(self, texts, padding=True, return_tensors="pt", return_attention_mask=True):
+        rows = [self.encode(t) for t in ([texts] if isinstance(texts, str) else texts)]
+        n = max(len(r) for r in rows)
+        # left padding, as generation tokenizers do (pipeline.py:1767 pads to a rectangle)
+        ids = torch.tensor([[self.pad_token_id] * (n - len(r)) + r for r in rows], dtype=torch.long)
+        mask = torch.tensor([[0] * (n - len(r)) + [1] * len(r) for r in rows], dtype=torch.long)
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+class HipLM(LanguageModel):
+    def __init__(self, weights: W.ModelWeights, tokenizer: Any = None, name: Optional[str] = None,
+                 max_len: int = 1024, batch: int = 1, device: str = "cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipLM needs a GPU: this build has no CPU compute path")
+        self._device = torch.device(device if device != "auto" else "cuda")
+        self.weights = weights if weights.tok_emb.device.type == "cuda" else weights.to(self._device)
+        self.config = self.weights.config
+        self.vocab_size = self.config.vocab
+        self._tokenizer = tokenizer or IdTokenizer(self.config.vocab, self.config.eos_token_id)
+        self._name = name or self.config.name
+        self._max_len, self._batch = max_len, batch
+        self._model: Optional[HipModel] = None
+        self._cached: List[List[int]] = []
+        self._last_generated_kv: Optional[KVCache] = None
+
+    # ---- engine instances ----------------------------------------------------------
+    def new_engine(self, batch: int, l_max: int) -> HipModel:
+        """A forward instance with its own KV cache over the shared weights."""
+        return HipModel(self.weights, batch=batch, l_max=l_max, device=self._device)
+
+    def _engine(self, batch: int, need_len: int) -> HipModel:
+        m = self._model
+        if m is None or m.batch < batch or m.l_max < need_len:
+            self._model = m = self.new_engine(max(batch, self._batch), max(need_len + 64, self._max_len))
+            self._cached = [[] for _ in range(m.batch)]
+        return m
+
+    # ---- LanguageModel -----------------------------------------------------------------
+    def generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, temperature: float = 0.7,
+                        do_sample: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """k tokens + their logits [B, k, V] (fp32), one forward per token
+        (hf_wrappers.py:272-627 semantics: argmax of the last position; with do_sample the
+        token is drawn from softmax(logits / T))."""
+        if input_ids.dim() == 1:
+            input_ids = input_ids.unsqueeze(0)
+        ids = validate_and_clamp_tokens(input_ids.long(), self.vocab_size, "generate_tokens")
+        B, L = ids.shape
+        m = self._engine(B, L + max_new_tokens + 1)
+        host = ids.cpu().tolist()
+        dev = self._device
+        out_ids, out_logits = [], []
+        # cache the prefix (all but the last token); reuse what is already there
+        for b in range(B):
+            have = self._cached[b]
+            common = 0
+            for x, y in zip(have, host[b][:-1]):
+                if x != y:
+                    break
+                common += 1
+            todo = host[b][common : L - 1]
+            if todo:
+                m.forward(torch.tensor([todo], dtype=torch.int32, device=dev),
+                          torch.tensor([common], dtype=torch.int32, device=dev), 0, skip_head=True, row0=b)
+            self._cached[b] = list(host[b][: L - 1])
+        cur = ids[:, -1:].to(dev, torch.int32).contiguous()
+        pos = torch.full((B,), L - 1, dtype=torch.int32, device=dev)
+        for _ in range(max_new_tokens):
+            nxt, logits = m.forward(cur, pos, 0, want_logits=True, logits_dtype=torch.float32)
+            last = logits[:, 0, :]
+            if do_sample and temperature and temperature > 0:
+                probs = torch.softmax(last / temperature, dim=-1)
+                nxt = torch.multinomial(probs, 1).to(torch.int32)
+            for b in range(B):
+                self._cached[b].append(int(cur[b, 0]))
+            out_ids.append(nxt.long())
+            out_logits.append(last)
+            cur = nxt.to(torch.int32).contiguous()
+            pos = pos + 1
+        if not out_ids:
+            return (torch.empty((B, 0), dtype=torch.long, device=dev),
+                    torch.empty((B, 0, self.vocab_size), dtype=torch.float32, device=dev))
+        return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
+
+    def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor):
+        """The K-token parallel verify as a wrapper call: one forward over
+        (last, d_1..d_K) -> (argmax ids [B, K+1], logits [B, K+1, V])."""
+        ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
+        B, L = ids.shape
+        K = draft_tokens.shape[1]
+        self.generate_tokens(ids, 0)  # caches the prefix
+        m = self._model
+        dev = self._device
+        toks = torch.cat([ids[:, -1:].to(dev), draft_tokens.to(dev)], dim=1).to(torch.int32).contiguous()
+        pos = torch.full((B,), L - 1, dtype=torch.int32, device=dev)
+        t_ids, logits = m.forward(toks, pos, 0, want_logits=True, logits_dtype=torch.float32)
+        return t_ids.long(), logits
+
+    def get_tokenizer_info(self) -> Dict[str, Any]:
+        t = self._tokenizer
+        return {
+            "vocab_size": self.vocab_size,
+            "pad_token_id": getattr(t, "pad_token_id", None),
+            "eos_token_id": getattr(t, "eos_token_id", self.config.eos_token_id),
+            "bos_token_id": getattr(t, "bos_token_id", None),
+            "model_name": self._name,
+            "tokenizer_type": type(t).__name__,
+        }
+
+    def encode(self, text: str) -> torch.Tensor:
+        t = self._tokenizer
+        ids = t.encode(text)
+        return torch.tensor([list(ids)], dtype=torch.long)
+
+    def decode(self, token_ids: Any) -> str:
+        if isinstance(token_ids, torch.Tensor):
+            token_ids = token_ids.flatten().tolist()
+        elif token_ids and isinstance(token_ids[0], (list, tuple)):
+            token_ids = list(token_ids[0])
+        return self._tokenizer.decode(list(token_ids), skip_special_tokens=True)
+
+    @property
+    def device(self) -> str:
+        return "cuda"
+
+    @property
+    def model_name(self) -> str:
+        return self._name
+
+    # ---- KV hooks ------------------------------------------------------------------------
+    def supports_kv_append(self) -> bool:
+        return True
+
+    def get_kv_cache(self) -> Optional[KVCache]:
+        m = self._model
+        if m is None or not self._cached or not self._cached[0]:
+            return None
+        n = len(self._cached[0])
+        k, v = m.kv_view()  # k [L,B,H,Lmax,D], v [L,B,H,D,Lmax]
+        kv = tuple((k[l, :, :, :n, :], v[l, :, :, :, :n].transpose(-1, -2)) for l in range(self.config.n_layers))
+        return KVCache(past_key_values=kv, seq_len=n, dtype=torch.bfloat16, device=self._device)
+
+    def get_last_generated_kv(self) -> Optional[KVCache]:
+        return self._last_generated_kv
+
+    def append_kv_cache(self, kv_chunk: Any) -> None:
+        """The forward appends in place; there is nothing to concatenate afterwards
+        (the reference re-copies the cache here, hf_wrappers.py:985-1029)."""
+        return None
+
+    def clear_kv_cache(self) -> None:
+        self._cached = [[] for _ in self._cached]
+        self._last_generated_kv = None
+
+    def optimize(self, *a, **k):
+        return self
+
+
+def create_hip_lm(spec: Any, device: str = "cuda", **kw) -> HipLM:
+    """`spec`: a ModelWeights, a local checkpoint directory, or "synthetic:<preset>"."""
+    if isinstance(spec, W.ModelWeights):
+        return HipLM(spec, device=device, **kw)
+    if isinstance(spec, str) and spec.startswith("synthetic:"):
+        preset = {"llama-3.2-1b": W.LLAMA_3_2_1B, "llama-3.2-3b": W.LLAMA_3_2_3B, "llama-3-8b": W.LLAMA_3_8B}[spec.split(":", 1)[1]]
+        return HipLM(W.synthetic_llama(preset, device=device), device=device, **kw)
+    import os
+
+    if isinstance(spec, str) and os.path.isdir(spec):
+        mw = W.load_checkpoint_dir(spec, device=device)
+        tok = None
+        try:
+            import transformers
+
+            tok = transformers.AutoTokenizer.from_pretrained(spec, local_files_only=True)
+        except Exception as e:  # tokenizer is optional plumbing; ids can be passed directly
+            logger.warning("no tokenizer loaded from %s (%s); using IdTokenizer", spec, e)
+        return HipLM(mw, tokenizer=tok, name=os.path.basename(spec.rstrip("/")), device=device, **kw)
+    raise ValueError(f"cannot build a HIP model from {spec!r}: pass ModelWeights, a local checkpoint directory, "
+                     f"or 'synthetic:<llama-3.2-1b|llama-3.2-3b|llama-3-8b>' (nothing is downloaded by name)")

@@ -78,25 +78,10 @@ def test_verify_forward_logits_with_ragged_rows():
     hm = _hip_model(tgt, batch=B, l_max=64)
     g = torch.Generator().manual_seed(8)
     seqs = [torch.randint(4, V, (n + M,), generator=g) for n in lens]
-    # prefill each row separately (positions 0..n-1), using its own row of the cache
+    # prefill each row separately (positions 0..n-1) into its own row of the cache (row0)
     for b, (n, s) in enumerate(zip(lens, seqs)):
-        toks = torch.zeros((B, n), dtype=torch.int32)
-        toks[b] = s[:n].to(torch.int32)
-        # only row b is meaningful: run a 1-row forward on a view of the batch
-        from specdec_hip import _abi
-        pos = torch.zeros(B, dtype=torch.int32, device="cuda")
-        t_dev = toks.cuda()
-        rc = hm.lib.sd_model_forward(hm.handle, t_dev[b:].data_ptr(), n, pos[b:].data_ptr(), 0, 1, n,
-                                     None, 0, None, _abi.SD_BF16, 1, torch.cuda.current_stream().cuda_stream)
-        assert rc == 0, _abi.last_error()
-        # shift the row into place: the call above wrote row 0 of the cache view starting at b
-        if b:
-            k, v = hm.kv_view()
-            k[:, b, :, :n] = k[:, 0, :, :n]
-            v[:, b, :, :, :n] = v[:, 0, :, :, :n]  # V cache is [.., D, Lmax]
-    # redo row 0 last so that its cache row is its own
-    toks0 = seqs[0][: lens[0]].to(torch.int32).view(1, -1).cuda()
-    hm.forward(toks0, torch.zeros(1, dtype=torch.int32, device="cuda"), 0, skip_head=True)
+        hm.forward(s[:n].to(torch.int32).view(1, -1).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), 0,
+                   skip_head=True, row0=b)
     new = torch.stack([s[n:] for n, s in zip(lens, seqs)], 0)
     pos = torch.tensor(lens, dtype=torch.int32, device="cuda")
     ids, logits = hm.forward(new.to(torch.int32).cuda(), pos, 0, want_logits=True)

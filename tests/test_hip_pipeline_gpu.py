@@ -1,0 +1,130 @@
+"""SpeculativePipeline on the GPU vs the oracle restatement of the reference loop and vs
+the reference's own traces (tests/golden/pipeline_golden.json). Token ids must be identical."""
+
+import json
+import os
+
+import pytest
+import torch
+
+import cases
+from helpers import synthetic_prompts, tiny_pair
+from oracle.model_ref import OracleLM
+from oracle.pipeline_ref import OraclePipeline
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pipe(drf, tgt, k, controller="fixed", controller_params=None):
+    from src.specdec import HipLM, SpeculativePipeline
+
+    return SpeculativePipeline(base_lm=HipLM(tgt.to("cuda")), draft_lm=HipLM(drf.to("cuda")),
+                               controller=controller, controller_params=controller_params or {"k": k}, seed=1234)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "pipeline_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("pname", ["structured", "repeating"])
+def test_pipeline_matches_oracle_and_reference_traces(pname, gold):
+    """bf16 weights on the GPU vs (a) the oracle loop on the same bf16 weights and (b) the
+    reference's fp32 CPU traces. The synthetic pairs have large argmax margins, so the
+    precision does not change a single token; 'repeating' drives the de-duplication rules
+    (rows rewound on the host -> cache rebuild on the device)."""
+    drf, tgt = cases.g8_pairs(torch.bfloat16)[pname]
+    base, draft = OracleLM(tgt, "bf16"), OracleLM(drf, "bf16")
+    for run in gold[pname]["runs"]:
+        k, mt, prompt = run["k"], run["max_tokens"], run["prompt_ids"]
+        pipe = _pipe(drf, tgt, k)
+        oracle = OraclePipeline(base, draft, k=k, eos_token_id=2)
+        got = pipe.generate_batch([prompt], max_tokens=mt, do_sample=False)[0]
+        want = oracle.generate_batch([prompt], mt)[0]
+        assert got["generated_tokens"] == want["generated_tokens"], (pname, k, mt)
+        assert (got["proposed"], got["accepted"], got["batch_metrics"]["total_steps"]) == \
+               (want["proposed"], want["accepted"], want["steps"])
+        assert got["sequence"] == want["sequence"]
+        ref = run["batch"]
+        assert got["generated_tokens"] == ref["generated_tokens"], "differs from the reference's own trace"
+        assert (got["proposed"], got["accepted"], got["batch_metrics"]["total_steps"]) == \
+               (ref["proposed"], ref["accepted"], ref["steps"])
+        gs = pipe.generate(prompt, max_tokens=mt, do_sample=False)
+        ws = oracle.generate(prompt, mt)
+        assert gs["generated_tokens"] == ws["generated_tokens"] == run["single"]["generated_tokens"]
+        assert (gs["proposed"], gs["accepted"], gs["steps"]) == (ws["proposed"], ws["accepted"], ws["steps"])
+        assert (gs["proposed"], gs["accepted"], gs["steps"]) == \
+               (run["single"]["proposed"], run["single"]["accepted"], run["single"]["steps"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_k_sweep_batch8_rows_are_independent(k):
+    """BASELINE config 3 shape (K sweep, batch 8) on a tiny pair: every row of the batch equals
+    the same prompt run alone, and equals the oracle."""
+    drf, tgt = tiny_pair(flip_fraction=0.25)
+    prompts = synthetic_prompts(8, 16, tgt.config.vocab).tolist()
+    pipe = _pipe(drf, tgt, k)
+    got = pipe.generate_batch(prompts, max_tokens=24, do_sample=False)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=k, eos_token_id=tgt.config.eos_token_id)
+    want = oracle.generate_batch(prompts, 24)
+    for b in range(8):
+        assert got[b]["generated_tokens"] == want[b]["generated_tokens"], (k, b)
+        assert (got[b]["proposed"], got[b]["accepted"]) == (want[b]["proposed"], want[b]["accepted"])
+    alone = pipe.generate_batch([prompts[3]], max_tokens=24, do_sample=False)[0]
+    assert alone["generated_tokens"] == got[3]["generated_tokens"]
+    acc = sum(r["accepted"] for r in got) / sum(r["proposed"] for r in got)
+    assert 0.0 < acc <= (k + 1) / k
+
+
+def test_ragged_prompts_and_result_keys():
+    drf, tgt = tiny_pair()
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(4, 1000, (n,), generator=g).tolist() for n in (3, 11, 7)]
+    pipe = _pipe(drf, tgt, 4)
+    got = pipe.generate_batch(prompts, max_tokens=10, do_sample=False)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4)
+    want = oracle.generate_batch(prompts, 10)
+    for g_, w_ in zip(got, want):
+        assert g_["generated_tokens"] == w_["generated_tokens"]
+    for key in ("prompt", "text", "generated_tokens", "num_generated", "batch_index", "batch_size", "latency_ms",
+                "total_time_ms", "tokens_per_sec", "throughput_tokens_per_sec", "acceptance_rate", "proposed",
+                "accepted", "draft_avg_ms", "verify_avg_ms", "batch_metrics", "kv_append_enabled", "kv_append_backend"):
+        assert key in got[0], key
+    single = pipe.generate(prompts[1], max_tokens=9, do_sample=False)
+    for key in ("text", "generated_tokens", "latency_ms", "proposed", "accepted", "acceptance_rate", "tokens_per_sec",
+                "steps", "verification_time_ms", "generation_time_ms", "kv_appended_tokens_total", "kv_append_time_ms",
+                "kv_append_enabled", "kv_append_backend", "mem_rss_mb", "policy", "controller", "impl", "device",
+                "dtype", "base_model", "draft_model", "draft_mode"):
+        assert key in single, key
+    assert single["generated_tokens"] == oracle.generate(prompts[1], 9)["generated_tokens"]
+    assert len(single["generated_tokens"]) <= 9 and single["accepted"] <= single["proposed"]
+
+
+def test_adaptive_controller_changes_k_mid_run():
+    drf, tgt = tiny_pair(flip_fraction=0.0)  # draft == target successor: everything accepted -> K grows
+    pipe = _pipe(drf, tgt, 2, controller="adaptive",
+                 controller_params={"initial_k": 2, "min_k": 1, "max_k": 4, "target_acceptance_rate": 0.5})
+    prompts = synthetic_prompts(2, 8, 1000).tolist()
+    got = pipe.generate_batch(prompts, max_tokens=40, do_sample=False)
+    lm = OracleLM(tgt, "bf16")
+    for b in range(2):
+        want, _ = lm.generate_tokens(torch.tensor([prompts[b]]), len(got[b]["generated_tokens"]))
+        assert got[b]["generated_tokens"] == want[0].tolist()
+    assert got[0]["batch_metrics"]["k"] > 2
+
+
+def test_loud_refusals():
+    drf, tgt = tiny_pair()
+    pipe = _pipe(drf, tgt, 2)
+    with pytest.raises(NotImplementedError, match="do_sample"):
+        pipe.generate_batch([[5, 6, 7]], max_tokens=4, do_sample=True)
+    from src.specdec import SpeculativePipeline
+
+    with pytest.raises(ValueError, match="implementation"):
+        SpeculativePipeline(implementation="fake")
+    import specdec
+    import src.specdec
+
+    assert specdec is src.specdec and specdec.SpecDecRunner is specdec.SpeculativePipeline
