@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — accepted tokens/sec + acceptance rate of the draft-then-verify loop.
+
+    python bench.py --gpus 1 --steps 40 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Llama-3.2-3B target + Llama-3.2-1B draft shapes, K = 4,
+batch 1 per GPU, bf16, synthetic prompts (32 ids, generator seed 1234+i) and architecture-
+exact synthetic weights (specdec_hip/weights.py: no checkpoints or datasets offline).
+A "step" is one draft-then-verify step of the product pipeline (one hipGraph replay +
+the host-side reference rules). EXACTLY --steps steps are timed between barrier +
+torch.cuda.synchronize() pairs; value = tokens emitted by all ranks / max-over-ranks time.
+With N > 1 every rank decodes its own prompts on its own GPU (data parallel over prompts,
+weak scaling, no collective in the data path) and the per-rank stats are all-gathered
+once over RCCL.
+
+One JSON line is printed by rank 0. Besides the contract keys it carries
+  roofline     — the dominant kernel (fused norm + gate/up + SwiGLU GEMV of the target at
+                 T = K+1 tokens) priced against HBM: algorithmic bytes N*K*2 per launch over
+                 its average launch duration, timed here with HIP events on the launch stream
+  cpu_baseline — the oracle's reference-faithful loop (2K full-prefix forwards per step, as
+                 the reference with KV append off) on the host cores, bounded sample
+  step_roofline_frac — (K*W_draft + W_target bytes) / step time / 8 TB/s for the whole step
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "llm-inference-lab_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_BPS = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+PROMPT_LEN = 32
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1, help="rows per GPU")
+    ap.add_argument("--target", default="llama-3.2-3b")
+    ap.add_argument("--draft", default="llama-3.2-1b")
+    ap.add_argument("--flip", type=float, default=0.2, help="fraction of tokens whose draft successor differs")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=6, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-probe", action="store_true")
+    return ap.parse_args()
+
+
+def build_models(args, device):
+    from specdec_hip import weights as W
+
+    presets = {"llama-3.2-1b": W.LLAMA_3_2_1B, "llama-3.2-3b": W.LLAMA_3_2_3B, "llama-3-8b": W.LLAMA_3_8B}
+    ckpt = os.environ.get("SPECDEC_MODEL_DIR")
+    if ckpt and os.path.isdir(os.path.join(ckpt, args.target)) and os.path.isdir(os.path.join(ckpt, args.draft)):
+        tgt = W.load_checkpoint_dir(os.path.join(ckpt, args.target), device=device)
+        drf = W.load_checkpoint_dir(os.path.join(ckpt, args.draft), device=device)
+        return drf, tgt, "checkpoint"
+    tgt = W.synthetic_llama(presets[args.target], seed=0, device=device)
+    drf = W.synthetic_llama(presets[args.draft], seed=1, device=device, embed_from=tgt, flip_fraction=args.flip)
+    return drf, tgt, "synthetic"
+
+
+def prompts_for(rank, batch, vocab):
+    out = []
+    for i in range(batch):
+        g = torch.Generator().manual_seed(1234 + rank * batch + i)
+        out.append(torch.randint(4, vocab, (PROMPT_LEN,), generator=g, dtype=torch.int64).tolist())
+    return out
+
+
+def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows):
+    """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample.
+    Returns the baseline dict and whether the GPU emitted the same tokens on those steps."""
+    from oracle.model_ref import OracleLM
+    from oracle.pipeline_ref import OraclePipeline
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # a 1-GPU box gives this job a 16-CPU share whatever the affinity mask says
+    cores = int(os.environ.get("SPECDEC_CPU_THREADS", min(cores, 16)))
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, copying weights to the host")
+    d_cpu, t_cpu = drf.to("cpu"), tgt.to("cpu")
+    base, draft = OracleLM(t_cpu, "bf16"), OracleLM(d_cpu, "bf16")
+    pipe = OraclePipeline(base, draft, k=k, eos_token_id=tgt.config.eos_token_id, reprefill=True)
+    # warm: materialise the fp32 weight copies outside the timed region
+    base.forward(torch.tensor([prompts[0][:2]]))
+    draft.forward(torch.tensor([prompts[0][:2]]))
+    log(f"cpu_baseline: timing {n_steps} reference-faithful step(s) on the host")
+    t0 = time.time()
+    res = pipe.generate_batch([prompts[0]], max_tokens=10 ** 6, max_steps=n_steps)[0]
+    dt = time.time() - t0
+    n = len(res["generated_tokens"])
+    same = gpu_rows[0][:n] == res["generated_tokens"]
+    return {
+        "value": n / dt if dt > 0 else 0.0, "unit": "tokens/s", "cores": cores, "kind": "port",
+        "sample": f"{res['steps']} steps of prompt 0 ({n} tokens, {dt:.1f} s): reference-faithful loop, "
+                  f"2K full-prefix forwards per step, bf16-rounded weights/activations with fp32 accumulation",
+        "acceptance_rate": res["acceptance_rate"],
+    }, bool(same)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback to time)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from src.specdec import HipLM, SpeculativePipeline
+    from specdec_hip.engine import HipSpecDec
+
+    log(f"rank {rank}/{world}: building {args.target} + {args.draft} weights on {device}")
+    drf, tgt, source = build_models(args, device)
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt), draft_lm=HipLM(drf), controller="fixed",
+                               controller_params={"k": args.k}, seed=1234)
+    K, B = args.k, args.batch
+    prompts = prompts_for(rank, B, tgt.config.vocab)
+    total_steps = args.warmup + args.steps
+    sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1, emit_mode=HipSpecDec.EMIT_BONUS)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("prefill done, warming up")
+    for _ in range(args.warmup):
+        sess.advance()
+    n0 = sum(len(r.generated) for r in sess.rows)
+    p0, a0 = sess.stats["proposed"], sum(r.accepted for r in sess.rows)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sess.advance()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    barrier()
+    n_tok = sum(len(r.generated) for r in sess.rows) - n0
+    proposed = sess.stats["proposed"] - p0
+    accepted_ref = sum(r.accepted for r in sess.rows) - a0          # reference definition (bonus counted)
+    accepted_strict = accepted_ref - args.steps * B                  # draft tokens accepted only
+    stats = torch.tensor([n_tok, proposed, accepted_ref, accepted_strict, int(dt_local * 1e9), args.steps],
+                         dtype=torch.int64, device=device)
+    if dist is not None:
+        gathered = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)  # the one collective: 48 bytes per rank over xGMI
+        allst = torch.stack(gathered).cpu()
+    else:
+        allst = stats.cpu().unsqueeze(0)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    t_max = float(allst[:, 4].max()) / 1e9
+    tokens = int(allst[:, 0].sum())
+    prop = int(allst[:, 1].sum())
+    value = tokens / t_max
+    ms_per_step = t_max / args.steps * 1e3
+    bytes_step = K * drf.matmul_bytes() + tgt.matmul_bytes()
+    out = {
+        "metric": "accepted tokens/sec + acceptance-rate, Llama-3.2-3B/1B K=4 @1/2/4/8 GPU",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, greedy, "
+                               f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
+                   "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
+                   "parallelism": f"dp{world}"},
+        "acceptance_rate": int(allst[:, 2].sum()) / max(prop, 1),
+        "acceptance_rate_strict": int(allst[:, 3].sum()) / max(prop, 1),
+        "tokens_per_step": tokens / (args.steps * world * B),
+        "step_bytes": bytes_step,
+        "step_roofline_frac": bytes_step / (ms_per_step / 1e3) / HBM_PEAK_BPS,
+        "resyncs": sess.stats["resyncs"],
+    }
+    log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} tok/s")
+    # ---- roofline of the dominant kernel, timed live with HIP events --------------------
+    if not args.no_probe:
+        tm = sess.rt["target"]
+        st = torch.cuda.Stream()
+        usec, nbytes = tm.probe_gemv(tm.PROBE_GATE_UP, T=min(B * (K + 1), 9), iters=280, stream=st)
+        ach = nbytes / (usec * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_mfma_kernel<EPI_SWIGLU> (target norm+gate/up+SwiGLU)",
+                           "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK_BPS,
+                           "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": usec}
+        others = {}
+        for name, which, T in (("target_lm_head", tm.PROBE_LM_HEAD, min(B * (K + 1), 9)),
+                               ("target_down", tm.PROBE_DOWN, min(B * (K + 1), 9)),
+                               ("target_o_proj", tm.PROBE_O, min(B * (K + 1), 9))):
+            u, nb = tm.probe_gemv(which, T=T, iters=140, stream=st)
+            others[name] = {"avg_launch_us": u, "GBps": nb / (u * 1e-6) / 1e9}
+        dmod = sess.rt["draft"]
+        for name, which in (("draft_gate_up", dmod.PROBE_GATE_UP), ("draft_lm_head", dmod.PROBE_LM_HEAD)):
+            u, nb = dmod.probe_gemv(which, T=B, iters=160, stream=st)
+            others[name] = {"avg_launch_us": u, "GBps": nb / (u * 1e-6) / 1e9}
+        out["roofline"]["other_kernels"] = others
+    # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------------------------
+    if world == 1 and args.cpu_baseline_steps > 0:
+        gpu_rows = [list(r.generated) for r in sess.rows]
+        cb, same = cpu_baseline(drf, tgt, prompts, K, args.cpu_baseline_steps, gpu_rows)
+        out["cpu_baseline"] = cb
+        out["parity_with_cpu_sample"] = same
+        out["speedup_vs_cpu_baseline"] = value / cb["value"] if cb["value"] > 0 else None
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -213,6 +213,14 @@ int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride,
                      int32_t* ids_out, int ids_stride,
                      void* logits_out, int logits_dtype, int skip_head, void* stream);
 
+/* Measurement hook for bench.py's roofline leg: launches ONE of the forward's weight-
+ * streaming GEMVs (which: 1 = attention out-proj, 2 = norm+gate/up+SwiGLU, 3 = down-proj,
+ * 4 = final norm+lm_head+argmax) `iters` times, round-robin over the layers so the weights
+ * stream from HBM, between two HIP events on `stream`; returns the average launch duration
+ * and the algorithmic bytes of one launch (N*K*2). Synchronises on the second event. */
+int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, void* stream,
+                        float* avg_usec, double* bytes_per_launch);
+
 /* ---- the step loop ------------------------------------------------------- */
 typedef struct sd_specdec sd_specdec;
 

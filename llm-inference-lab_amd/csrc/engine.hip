@@ -339,6 +339,77 @@ extern "C" int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stri
                        logits_dtype, skip_head, static_cast<hipStream_t>(stream));
 }
 
+// Measurement hook (bench.py "roofline" leg): one GEMV of the forward, launched `iters`
+// times round-robin over the layers (so the weights come from HBM, not from the 256 MiB
+// Infinity Cache) between two HIP events on `stream`.
+extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, void* stream, float* avg_usec,
+                                   double* bytes_per_launch) {
+  clear_error();
+  SD_REQUIRE(m && m->x && avg_usec && bytes_per_launch, "probe_gemv: NULL argument / model not bound");
+  SD_REQUIRE(T >= 1 && T <= kGemvMaxT && iters >= 1, "probe_gemv: T=%d iters=%d", T, iters);
+  const sd_model_config& c = m->cfg;
+  const bool llama = (c.arch == SD_ARCH_LLAMA);
+  const int d = c.d_model, ff = c.d_ff, Hq = c.n_heads, D = c.head_dim;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  SD_HIP_CHECK(hipEventCreate(&e0));
+  SD_HIP_CHECK(hipEventCreate(&e1));
+  auto launch = [&](int l) -> int {
+    const sd_layer_weights& w = m->layers[l % c.n_layers];
+    GemvArgs g{};
+    g.T = T;
+    g.M = T;
+    g.out_dtype = SD_BF16;
+    g.norm_eps = c.norm_eps;
+    switch (which) {
+      case 1:  // attention output projection + residual
+        g.W = w.wo; g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
+        g.x = m->attn; g.x_stride = Hq * D; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
+        return launch_gemv(g, EPI_RESID, st);
+      case 2:  // norm + gate/up + SwiGLU (GELU for GPT-2)
+        g.W = w.w_up; g.bias = w.b_up; g.K = d; g.x = m->x; g.x_stride = d;
+        g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.mlp_norm_w; g.norm_b = w.mlp_norm_b;
+        g.out = m->act; g.out_stride = ff;
+        if (llama) { g.N = 2 * ff; g.n_pairs = ff; return launch_gemv(g, EPI_SWIGLU, st); }
+        g.N = ff; g.n_pairs = ff / 2;
+        return launch_gemv(g, EPI_GELU, st);
+      case 3:  // down projection + residual
+        g.W = w.w_down; g.bias = w.b_down; g.N = d; g.K = ff; g.n_pairs = d / 2;
+        g.x = m->act; g.x_stride = ff; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
+        return launch_gemv(g, EPI_RESID, st);
+      case 4:  // final norm + lm_head + fused argmax
+        g.W = c.lm_head; g.N = c.vocab; g.K = d; g.n_pairs = (c.vocab + 1) / 2; g.x = m->x; g.x_stride = d;
+        g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = c.final_norm_w; g.norm_b = c.final_norm_b;
+        g.part_val = m->part_val; g.part_idx = m->part_idx;
+        return launch_gemv(g, EPI_ARGMAX, st);
+      default:
+        set_error("probe_gemv: which=%d (1=o_proj 2=gate_up 3=down 4=lm_head)", which);
+        return 1;
+    }
+  };
+  double bytes = 0;
+  switch (which) {
+    case 1: bytes = 2.0 * d * Hq * D; break;
+    case 2: bytes = 2.0 * (llama ? 2 : 1) * ff * d; break;
+    case 3: bytes = 2.0 * d * ff; break;
+    default: bytes = 2.0 * c.vocab * d; break;
+  }
+  for (int i = 0; i < 3; ++i)
+    if (int rc = launch(i)) return rc;
+  SD_HIP_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i)
+    if (int rc = launch(i + 3)) return rc;
+  SD_HIP_CHECK(hipEventRecord(e1, st));
+  SD_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_usec = ms * 1000.0f / iters;
+  *bytes_per_launch = bytes;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------- step loop
 struct sd_specdec {
   sd_model* draft = nullptr;

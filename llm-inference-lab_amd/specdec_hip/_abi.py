@@ -67,6 +67,8 @@ SIGNATURES = {
         [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
          _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     ),
+    "sd_model_probe_gemv": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]),
     "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "sd_specdec_destroy": (_c_int, [_c_void_p]),
     "sd_specdec_set_row": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),

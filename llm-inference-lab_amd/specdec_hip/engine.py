@@ -121,6 +121,18 @@ class HipModel:
         _abi.check(rc, "sd_model_forward")
         return ids, logits
 
+    PROBE_O, PROBE_GATE_UP, PROBE_DOWN, PROBE_LM_HEAD = 1, 2, 3, 4
+
+    def probe_gemv(self, which: int, T: int, iters: int = 200, stream: Optional[torch.cuda.Stream] = None):
+        """(average launch duration in microseconds, algorithmic bytes per launch) of one of the
+        forward's GEMVs, timed with HIP events on the launch stream (sd_model_probe_gemv)."""
+        usec, nbytes = ctypes.c_float(0), ctypes.c_double(0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.sd_model_probe_gemv(self.handle, int(which), int(T), int(iters), _stream(stream, self.device),
+                                              ctypes.byref(usec), ctypes.byref(nbytes))
+        _abi.check(rc, "sd_model_probe_gemv")
+        return float(usec.value), float(nbytes.value)
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.sd_model_destroy(self.handle)

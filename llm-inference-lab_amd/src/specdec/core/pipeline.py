@@ -245,74 +245,22 @@ class SpeculativePipeline:
             row.active = False
 
     # ------------------------------------------------------------------ the loop
+    def start_session(self, prompts: List[List[int]], max_tokens: int, emit_mode: int) -> "DecodeSession":
+        """Prefill + device state for a batch of rows; `advance()` then runs one step at a time
+        (generate / generate_batch drive it to completion, bench.py times exact step counts)."""
+        return DecodeSession(self, prompts, max_tokens, emit_mode)
+
     def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int):
-        B = len(prompts)
-        rows = [_Row(list(p)) for p in prompts]
-        for r in rows:
-            if not r.seq:
-                raise ValueError("empty prompt")
-        eos = self.base_lm.get_tokenizer_info().get("eos_token_id")
-        k_max = getattr(self.controller, "max_k", None) or getattr(self.controller, "k", 4)
-        need = max(len(r.seq) for r in rows) + max_tokens + 2 * int(k_max) + 8
         t_start = time.time()
-        k = int(self.controller.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
-        rt, loop = self._runtime(B, need, k, emit_mode)
-        self._prefill(rt, rows)
-        loop.join_current_stream()
-        for b, r in enumerate(rows):
-            self._set_row(loop, b, r)
-        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0}
-        step = 0
-        while step < step_limit and any(r.active for r in rows):
-            step += 1
-            if step > 1:
-                ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
-                       "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
-                k_new = int(self.controller.get_k(step, ctx))
-                if k_new <= 0:
-                    break
-                if k_new != k:  # adaptive K: another captured step over the same caches
-                    loop.sync()
-                    k = k_new
-                    rt, loop = self._runtime(B, need, k, emit_mode)
-                    loop.join_current_stream()
-                    for b, r in enumerate(rows):
-                        self._set_row(loop, b, r)
-            t0 = time.time()
-            loop.step(use_graph=True)
-            rec = loop.sync()
-            stats["device_ms"] += (time.time() - t0) * 1e3
-            for b, r in enumerate(rows):
-                if not r.active:
-                    continue
-                a = int(rec.accept_len[b])
-                t = [int(x) for x in rec.target_ids[b]]
-                d = [int(x) for x in rec.draft_tokens[b]]
-                before, acc0 = r.seq, r.accepted
-                n_new = int(rec.n_new[b])
-                assumed = before + t[:n_new]  # what the device advanced to
-                if emit_mode == HipSpecDec.EMIT_BONUS:
-                    self._rules_batch(r, k, a, t, max_tokens, eos)
-                else:
-                    self._rules_single(r, k, a, d, t, max_tokens, eos)
-                stats["proposed"] += k
-                stats["accepted"] += r.accepted - acc0
-                if not r.active:
-                    self._set_row(loop, b, r)       # freeze the row on the device
-                elif r.seq != assumed:
-                    stats["resyncs"] += 1           # the host rules rewrote the row: rebuild its caches
-                    loop.sync()
-                    self._prefill_row(rt, b, r.seq)
-                    loop.join_current_stream()
-                    self._set_row(loop, b, r)
-                if len(r.seq) + 2 * k + 4 > rt["l_max"]:
-                    r.active = False
-                    self._set_row(loop, b, r)
-            stats["steps"] = step
+        sess = self.start_session(prompts, max_tokens, emit_mode)
+        while sess.step < step_limit and sess.any_active():
+            if not sess.advance():
+                break
         torch.cuda.synchronize()
-        stats["total_ms"] = (time.time() - t_start) * 1e3
-        stats["k"] = k
-        return rows, stats
+        st = sess.stats
+        st["total_ms"] = (time.time() - t_start) * 1e3
+        st["k"] = sess.k
+        return sess.rows, st
 
     # ------------------------------------------------------------------ public API
     def _check_sampling(self, do_sample: bool) -> None:
@@ -401,3 +349,81 @@ class SpeculativePipeline:
             "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name,
             "draft_mode": self.config.get("draft_mode", "vanilla"),
         }
+
+
+class DecodeSession:
+    """One batch of rows being decoded: host mirror of the sequences + the device loop."""
+
+    def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int):
+        self.pipe, self.max_tokens, self.emit_mode = pipe, max_tokens, emit_mode
+        self.rows = [_Row(list(p)) for p in prompts]
+        for r in self.rows:
+            if not r.seq:
+                raise ValueError("empty prompt")
+        self.eos = pipe.base_lm.get_tokenizer_info().get("eos_token_id")
+        ctl = pipe.controller
+        k_max = getattr(ctl, "max_k", None) or getattr(ctl, "k", 4)
+        self.need = max(len(r.seq) for r in self.rows) + max_tokens + 2 * int(k_max) + 8
+        self.k = int(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
+        self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode)
+        pipe._prefill(self.rt, self.rows)
+        self.loop.join_current_stream()
+        for b, r in enumerate(self.rows):
+            pipe._set_row(self.loop, b, r)
+        self.stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0}
+        self.step = 0
+
+    def any_active(self) -> bool:
+        return any(r.active for r in self.rows)
+
+    def advance(self) -> bool:
+        """One draft-then-verify step for every active row. Returns False when the controller
+        stops the run."""
+        pipe, rows, stats = self.pipe, self.rows, self.stats
+        self.step += 1
+        step = self.step
+        if step > 1:
+            ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
+                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+            k_new = int(pipe.controller.get_k(step, ctx))
+            if k_new <= 0:
+                return False
+            if k_new != self.k:  # adaptive K: another captured step over the same caches
+                self.loop.sync()
+                self.k = k_new
+                self.rt, self.loop = pipe._runtime(len(rows), self.need, self.k, self.emit_mode)
+                self.loop.join_current_stream()
+                for b, r in enumerate(rows):
+                    pipe._set_row(self.loop, b, r)
+        k, loop, rt = self.k, self.loop, self.rt
+        t0 = time.time()
+        loop.step(use_graph=True)
+        rec = loop.sync()
+        stats["device_ms"] += (time.time() - t0) * 1e3
+        for b, r in enumerate(rows):
+            if not r.active:
+                continue
+            a = int(rec.accept_len[b])
+            t = [int(x) for x in rec.target_ids[b]]
+            d = [int(x) for x in rec.draft_tokens[b]]
+            before, acc0 = r.seq, r.accepted
+            assumed = before + t[: int(rec.n_new[b])]  # what the device advanced to
+            if self.emit_mode == HipSpecDec.EMIT_BONUS:
+                pipe._rules_batch(r, k, a, t, self.max_tokens, self.eos)
+            else:
+                pipe._rules_single(r, k, a, d, t, self.max_tokens, self.eos)
+            stats["proposed"] += k
+            stats["accepted"] += r.accepted - acc0
+            if not r.active:
+                pipe._set_row(loop, b, r)       # freeze the row on the device
+            elif r.seq != assumed:
+                stats["resyncs"] += 1           # the host rules rewrote the row: rebuild its caches
+                loop.sync()
+                pipe._prefill_row(rt, b, r.seq)
+                loop.join_current_stream()
+                pipe._set_row(loop, b, r)
+            if r.active and len(r.seq) + 2 * k + 4 > rt["l_max"]:
+                r.active = False
+                pipe._set_row(loop, b, r)
+        stats["steps"] = step
+        return True

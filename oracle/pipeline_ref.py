@@ -184,12 +184,14 @@ class OraclePipeline:
         a = longest_prefix(draft, t)
         return draft, t, a
 
-    def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int) -> List[Dict]:
+    def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int,
+                       max_steps: Optional[int] = None) -> List[Dict]:
+        """`max_steps` (not in the reference) bounds a timing sample to a number of steps."""
         rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
         self.trace = []
         t0 = time.time()
         step = 0
-        while step < max_tokens:                              # :1984 bound is STEPS, not tokens
+        while step < max_tokens and (max_steps is None or step < max_steps):   # :1984 bound is STEPS, not tokens
             step += 1
             if not any(r.active for r in rows):
                 break
