@@ -168,22 +168,19 @@ def main():
     proposed = sess.stats["proposed"] - p0
     accepted_ref = sum(r.accepted for r in sess.rows) - a0          # reference definition (bonus counted)
     accepted_strict = accepted_ref - args.steps * B                  # draft tokens accepted only
-    stats = torch.tensor([n_tok, proposed, accepted_ref, accepted_strict, int(dt_local * 1e9), args.steps],
-                         dtype=torch.int64, device=device)
-    if dist is not None:
-        gathered = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)  # the one collective: 48 bytes per rank over xGMI
-        allst = torch.stack(gathered).cpu()
-    else:
-        allst = stats.cpu().unsqueeze(0)
+    from specdec_hip.dist_stats import gather_stats
+
+    # the one collective of the job: a 48-byte struct per rank, all-gathered over RCCL/xGMI
+    job = gather_stats({"tokens": n_tok, "proposed": proposed, "accepted": accepted_ref,
+                        "accepted_strict": accepted_strict, "wall_ns": int(dt_local * 1e9), "steps": args.steps}, device)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    t_max = float(allst[:, 4].max()) / 1e9
-    tokens = int(allst[:, 0].sum())
-    prop = int(allst[:, 1].sum())
-    value = tokens / t_max
+    t_max = job.max_wall_s()
+    tokens = job.total("tokens")
+    prop = job.total("proposed")
+    value = job.tokens_per_s()
     ms_per_step = t_max / args.steps * 1e3
     bytes_step = K * drf.matmul_bytes() + tgt.matmul_bytes()
     out = {
@@ -195,8 +192,8 @@ def main():
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},
-        "acceptance_rate": int(allst[:, 2].sum()) / max(prop, 1),
-        "acceptance_rate_strict": int(allst[:, 3].sum()) / max(prop, 1),
+        "acceptance_rate": job.acceptance(),                 # reference definition: bonus token counted
+        "acceptance_rate_strict": job.acceptance(True),      # draft tokens accepted / proposed
         "tokens_per_step": tokens / (args.steps * world * B),
         "step_bytes": bytes_step,
         "step_roofline_frac": bytes_step / (ms_per_step / 1e3) / HBM_PEAK_BPS,
