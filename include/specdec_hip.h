@@ -179,7 +179,17 @@ typedef struct sd_model_config {
   const float* rope_cos;    /* [max_pos][D/2] fp32, Llama only */
   const float* rope_sin;
   const sd_layer_weights* layers; /* host array [n_layers] (copied by sd_model_create) */
+  const void* packed;       /* optional: buffer written by sd_pack_weights for THIS config; the
+                               GEMVs then stream the packed copy (the row-major matrices are no
+                               longer read by the forward, except tok_emb for the gather) */
 } sd_model_config;
+
+/* Weight pre-packing: the engine's private copy of all Linear weights in the order the
+ * streaming GEMV consumes them (csrc/pack.hip), so that every wave reads one contiguous
+ * region of HBM. sd_packed_bytes gives the buffer size (device memory, 256-byte aligned);
+ * sd_pack_weights fills it (asynchronous on `stream`). */
+size_t sd_packed_bytes(const sd_model_config* cfg);
+int sd_pack_weights(const sd_model_config* cfg, void* dst, size_t dst_bytes, void* stream);
 
 typedef struct sd_model sd_model;
 

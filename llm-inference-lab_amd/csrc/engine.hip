@@ -16,6 +16,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -36,6 +38,9 @@ struct sd_model {
   float* part_val = nullptr; // [9][512]
   int* part_idx = nullptr;
   int head_grid = 0;         // grid of the last lm_head launch (partials per token)
+  std::vector<const void*> packed;  // per matrix (4 per layer + lm_head) or empty: row-major weights
+  const void* mat(int index, const void* row_major) const { return packed.empty() ? row_major : packed[index]; }
+  int is_packed() const { return packed.empty() ? 0 : 1; }
 };
 
 namespace sd {
@@ -99,8 +104,9 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     g.out_dtype = SD_BF16;
 
     // 1. norm + QKV projection + RoPE + in-place KV append
+    g.packed = m->is_packed();
     GemvArgs a1 = g;
-    a1.W = w.wqkv;
+    a1.W = m->mat(4 * l + 0, w.wqkv);
     a1.bias = w.bqkv;
     a1.N = (Hq + 2 * Hkv) * D;
     a1.K = d;
@@ -138,7 +144,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
 
     // 3. output projection + residual
     GemvArgs a3 = g;
-    a3.W = w.wo;
+    a3.W = m->mat(4 * l + 1, w.wo);
     a3.bias = w.bo;
     a3.N = d;
     a3.K = Hq * D;
@@ -152,7 +158,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
 
     // 4. norm + up projection (+ gate) + activation
     GemvArgs a4 = g;
-    a4.W = w.w_up;
+    a4.W = m->mat(4 * l + 2, w.w_up);
     a4.bias = w.b_up;
     a4.K = d;
     a4.x = m->x;
@@ -175,7 +181,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
 
     // 5. down projection + residual
     GemvArgs a5 = g;
-    a5.W = w.w_down;
+    a5.W = m->mat(4 * l + 3, w.w_down);
     a5.bias = w.b_down;
     a5.N = d;
     a5.K = ff;
@@ -191,7 +197,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
 
   // final norm + lm_head with the argmax fused into the epilogue
   GemvArgs h{};
-  h.W = c.lm_head;
+  h.packed = m->is_packed();
+  h.W = m->mat(4 * c.n_layers, c.lm_head);
   h.N = c.vocab;
   h.K = d;
   h.n_pairs = (c.vocab + 1) / 2;
@@ -286,6 +293,10 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
       SD_REQUIRE(false, "model_create: layer %d has NULL weights", l);
     }
   }
+  if (cfg->packed) {
+    const char* base = static_cast<const char*>(cfg->packed);
+    for (int i = 0; i <= 4 * cfg->n_layers; ++i) m->packed.push_back(base + packed_offset(m->cfg, i));
+  }
   *out = m;
   return 0;
 }
@@ -354,31 +365,40 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
   hipEvent_t e0, e1;
   SD_HIP_CHECK(hipEventCreate(&e0));
   SD_HIP_CHECK(hipEventCreate(&e1));
+  unsigned long long* dbg = nullptr;
+  const bool timeline = getenv("SPECDEC_GEMV_TIMELINE") != nullptr;
+  if (timeline) {
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * sizeof(unsigned long long)));
+    SD_HIP_CHECK(hipMemset(dbg, 0, 256 * 8 * sizeof(unsigned long long)));
+  }
   auto launch = [&](int l) -> int {
     const sd_layer_weights& w = m->layers[l % c.n_layers];
     GemvArgs g{};
+    g.debug_ts = dbg;
+    g.packed = m->is_packed();
+    const int li = l % c.n_layers;
     g.T = T;
     g.M = T;
     g.out_dtype = SD_BF16;
     g.norm_eps = c.norm_eps;
     switch (which) {
       case 1:  // attention output projection + residual
-        g.W = w.wo; g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
+        g.W = m->mat(4 * li + 1, w.wo); g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
         g.x = m->attn; g.x_stride = Hq * D; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
         return launch_gemv(g, EPI_RESID, st);
       case 2:  // norm + gate/up + SwiGLU (GELU for GPT-2)
-        g.W = w.w_up; g.bias = w.b_up; g.K = d; g.x = m->x; g.x_stride = d;
+        g.W = m->mat(4 * li + 2, w.w_up); g.bias = w.b_up; g.K = d; g.x = m->x; g.x_stride = d;
         g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.mlp_norm_w; g.norm_b = w.mlp_norm_b;
         g.out = m->act; g.out_stride = ff;
         if (llama) { g.N = 2 * ff; g.n_pairs = ff; return launch_gemv(g, EPI_SWIGLU, st); }
         g.N = ff; g.n_pairs = ff / 2;
         return launch_gemv(g, EPI_GELU, st);
       case 3:  // down projection + residual
-        g.W = w.w_down; g.bias = w.b_down; g.N = d; g.K = ff; g.n_pairs = d / 2;
+        g.W = m->mat(4 * li + 3, w.w_down); g.bias = w.b_down; g.N = d; g.K = ff; g.n_pairs = d / 2;
         g.x = m->act; g.x_stride = ff; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
         return launch_gemv(g, EPI_RESID, st);
       case 4:  // final norm + lm_head + fused argmax
-        g.W = c.lm_head; g.N = c.vocab; g.K = d; g.n_pairs = (c.vocab + 1) / 2; g.x = m->x; g.x_stride = d;
+        g.W = m->mat(4 * c.n_layers, c.lm_head); g.N = c.vocab; g.K = d; g.n_pairs = (c.vocab + 1) / 2; g.x = m->x; g.x_stride = d;
         g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = c.final_norm_w; g.norm_b = c.final_norm_b;
         g.part_val = m->part_val; g.part_idx = m->part_idx;
         return launch_gemv(g, EPI_ARGMAX, st);
@@ -407,6 +427,26 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
   (void)hipEventDestroy(e1);
   *avg_usec = ms * 1000.0f / iters;
   *bytes_per_launch = bytes;
+  if (timeline) {  // stamps of the LAST launch: offsets from the earliest workgroup entry, in us
+    std::vector<unsigned long long> h(256 * 8);
+    SD_HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
+    unsigned long long t0 = ~0ull;
+    int n = 0;
+    for (int b = 0; b < 256; ++b)
+      if (h[b * 8]) { t0 = h[b * 8] < t0 ? h[b * 8] : t0; ++n; }
+    static const char* names[7] = {"entry", "issued", "staged", "mfma_done", "reduced", "epilogue", "end"};
+    fprintf(stderr, "[timeline which=%d T=%d] %d workgroups, us from first entry (min / mean / max):\n", which, T, n);
+    for (int s = 0; s < 7; ++s) {
+      double mn = 1e30, mx = 0, sum = 0;
+      for (int b = 0; b < 256; ++b) {
+        if (!h[b * 8]) continue;
+        const double v = (h[b * 8 + s] - t0) / 100.0;
+        mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v;
+      }
+      fprintf(stderr, "  %-10s %7.2f %7.2f %7.2f\n", names[s], mn, sum / (n ? n : 1), mx);
+    }
+  }
   return 0;
 }
 

@@ -41,7 +41,7 @@ namespace sd {
 constexpr int kGemvThreads = 1024;
 constexpr int kGemvWaves = kGemvThreads / kWave;  // 16 waves: 4 per SIMD
 constexpr int kBatch = 12;                        // loads in flight per lane
-constexpr int kTilePairs = 8;
+
 constexpr int kXPad = 8;                          // bf16 elements of padding per staged x row
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   float* part = reinterpret_cast<float*>(a.alias_part ? smem : smem + xs_bytes);  // [16 waves][16][16]
   float* red = reinterpret_cast<float*>(smem + xs_bytes + (a.alias_part ? 0 : sizeof(float) * kGemvWaves * 256));
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, kept in SGPRs
   const int g = lane >> 4, n = lane & 15;
   const int ksplit = a.ksplit;                 // power of two, <= 16
   const int tiles_per_round = kGemvWaves / ksplit;
@@ -276,8 +277,23 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   // lane's weight row inside a tile: rows 0..7 = first rows of the pairs, 8..15 = second
   // rows. Lanes without a pair alias the tile's first row (same address as lane 0: no
   // extra traffic); their results are never read.
-  auto row_ptr = [&](int tile) -> const uint16_t* {
+  // Address of a lane's A fragment = wave-uniform base (SGPRs) + 32-bit lane offset (one VGPR)
+  // + step * wstride. Packed weights (csrc/pack.hip): every 32-k step of a tile is one
+  // contiguous block [g][row] of 2*np*64 bytes; row-major: the lane offset selects the row.
+  int wstride = 32;  // elements between a lane's consecutive k-steps
+  const int K32 = (K + 31) & ~31;
+  unsigned lane_off = 0;
+  auto tile_base = [&](int tile) -> const uint16_t* {
     const int p0 = p_lo + tile * tile_pairs;
+    if (a.packed) {
+      int np = min(tile_pairs, p_hi - p0);
+      if (np < 1) np = 1;
+      int jp = n & 7, second = n >> 3;
+      if (jp >= np) { jp = 0; second = 0; }  // alias a valid lane: same address, no extra traffic
+      wstride = np * 64;
+      lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
+      return W + static_cast<size_t>(p0) * 2 * K32 + static_cast<size_t>(k_begin >> 5) * wstride;
+    }
     int p = p0 + (n & 7);
     int second = n >> 3;
     if ((n & 7) >= tile_pairs || p >= p_hi) { p = min(p0, p_hi - 1); second = 0; }
@@ -285,27 +301,36 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     pair_rows<EPI>(a, p, r0, r1);
     int r = second ? r1 : r0;
     if (r >= a.N) r = r0;  // odd N (vocabulary): second row of the last pair
-    return W + static_cast<size_t>(r) * K + k_begin + g * 8;
+    lane_off = static_cast<unsigned>(r) * static_cast<unsigned>(K) + static_cast<unsigned>(g * 8);
+    return W + k_begin;
   };
 
   u32x4 buf[kBatch];
-  auto issue = [&](const uint16_t* wrow, int s0) {
+  auto issue = [&](const uint16_t* ubase, int s0) {
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
       const int s = s0 + j;
       bool ok = s < steps;  // wave-uniform
-      if constexpr (MASK) ok = ok && (k_begin + s * 32 + g * 8 + 8 <= K);
-      if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 32));
+      if constexpr (MASK) ok = ok && (a.packed ? (k_begin + s * 32 < K32) : (k_begin + s * 32 + g * 8 + 8 <= K));
+      if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + static_cast<size_t>(s) * wstride + lane_off));
       else buf[j] = u32x4{0u, 0u, 0u, 0u};
     }
   };
 
+  // diagnostic timeline (sd_model_probe_gemv with SPECDEC_GEMV_TIMELINE=1): 100 MHz stamps
+  // of wave 0 / lane 0 into a buffer nothing else reads; no stamp executes otherwise
+  auto stamp = [&](int slot) {
+    if (a.debug_ts && tid == 0) a.debug_ts[static_cast<size_t>(blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   // start the weight stream before x is staged: HBM latency hides under the prologue
   const bool first_valid = tslot < n_tiles;
-  const uint16_t* wrow0 = row_ptr(first_valid ? tslot : 0);
+  const uint16_t* wrow0 = tile_base(first_valid ? tslot : 0);
   if (first_valid) issue(wrow0, 0);
+  stamp(1);
 
   stage_x(a, xs, KP, red);
+  stamp(2);
 
   float best_v = -INFINITY;
   int best_i = 0x7fffffff;
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     const int tile = r * tiles_per_round + tslot;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (tile < n_tiles) {
-      const uint16_t* wrow = (r == 0) ? wrow0 : row_ptr(tile);
+      const uint16_t* wrow = (r == 0) ? wrow0 : tile_base(tile);
       for (int s0 = 0; s0 < steps; s0 += kBatch) {
         if (r != 0 || s0 != 0) issue(wrow, s0);
 #pragma unroll
@@ -336,12 +361,14 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         }
       }
     }
+    if (r == 0) stamp(3);
     // publish this wave's partial 16x16 (row = 4g+reg, col = token n)
     if (a.alias_part) __syncthreads();  // every wave is done reading x
     float* slot = part + wave * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) slot[(4 * g + q) * 16 + n] = acc[q];
     __syncthreads();
+    if (r == 0) stamp(4);
     // epilogue items: thread -> (tile slot, pair, token); sums the ksplit slices
     for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
       const int ts = it >> 7, jp = (it >> 4) & 7, t = it & 15;  // t == tid & 15 on every trip
@@ -359,8 +386,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i);
       }
     }
+    if (r == 0) stamp(5);
     if (r + 1 < rounds) __syncthreads();  // partial slots are rewritten next round
   }
+  stamp(6);
 
   if constexpr (EPI == EPI_ARGMAX) {
     // thread tid holds a running best for token tid & 15 (pairs (tid>>4)&7 of its tile
@@ -394,14 +423,10 @@ static size_t gemv_smem(int T, int K, bool alias) {
   return (alias ? (xs > part ? xs : part) : xs + part) + red;
 }
 
-// one workgroup (16 waves) per CU with an equal, contiguous share of the row pairs
 int gemv_grid(const GemvArgs& a, int* ppw_out) {
-  int grid = 256;
-  if (a.n_pairs < grid) grid = a.n_pairs;
-  const int ppw = (a.n_pairs + grid - 1) / grid;
-  grid = (a.n_pairs + ppw - 1) / ppw;
-  *ppw_out = ppw;
-  return grid;
+  const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
+  *ppw_out = q.ppw;
+  return q.grid;
 }
 
 template <int EPI, bool MASK>
@@ -428,17 +453,14 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
   SD_REQUIRE(a.T >= 1 && a.T <= kGemvMaxT, "gemv: T=%d out of range 1..%d", a.T, kGemvMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemv: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
   SD_REQUIRE(a.n_pairs > 0, "gemv: no rows");
-  int ppw = 0;
-  const int grid = gemv_grid(a, &ppw);
-  a.ppw = ppw;
-  // tiles: a power-of-two count of <= 8-pair tiles; the 16 waves take (tile, K-slice) units
-  int n_tiles = 1;
-  while (n_tiles * kTilePairs < ppw) n_tiles <<= 1;
-  a.tile_pairs = (ppw + n_tiles - 1) / n_tiles;
-  int ksplit = kGemvWaves / (n_tiles < kGemvWaves ? n_tiles : kGemvWaves);
-  while (ksplit > 1 && (a.K + ksplit * 32 - 1) / (ksplit * 32) < 2) ksplit >>= 1;  // >= 2 steps per slice
-  a.ksplit = ksplit;
-  a.kw = ((a.K + ksplit * 32 - 1) / (ksplit * 32)) * 32;
+  // one workgroup (16 waves) per CU with an equal, contiguous share of the row pairs, cut into
+  // a power-of-two count of <= 8-pair tiles; the 16 waves take (tile, K-slice) units
+  const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
+  const int grid = q.grid, n_tiles = q.n_tiles, ksplit = q.ksplit;
+  a.ppw = q.ppw;
+  a.tile_pairs = q.tile_pairs;
+  a.ksplit = q.ksplit;
+  a.kw = q.kw;
   const bool mask = (a.kw * ksplit != a.K);
   size_t smem = gemv_smem(a.T, a.K, false);
   a.alias_part = 0;

@@ -1,6 +1,8 @@
 // Internal kernel-launch interfaces shared by the engine (not part of the C-ABI).
 #pragma once
 
+#include <vector>
+
 #include "common.h"
 
 namespace sd {
@@ -22,6 +24,8 @@ struct GemvArgs {
   int tile_pairs;    // pairs per tile, <= 8 (set by launch_gemv)
   int ksplit;        // K slices per tile, power of two <= 16 (set by launch_gemv)
   int alias_part;    // partial sums alias the staged x rows (set by launch_gemv)
+  unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
+  int packed;                    // W is in the packed tile-stream order of csrc/pack.hip
   // activations in: bf16 [T][x_stride]
   const void* x;
   int x_stride;
@@ -52,6 +56,13 @@ struct GemvArgs {
 };
 
 
+// work split of one matrix over the chip (shared by the launcher and the weight packer)
+struct GemvGeom {
+  int grid, ppw, n_tiles, tile_pairs, ksplit, kw;
+};
+GemvGeom gemv_geometry(int n_pairs, int K);
+size_t packed_matrix_bytes(int n_pairs, int K);
+size_t packed_offset(const sd_model_config& c, int index);  // index: 4*layer + {0 qkv,1 out,2 up,3 down}; 4*n_layers = lm_head
 int gemv_grid(const GemvArgs& a, int* ppw_out);
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);
 

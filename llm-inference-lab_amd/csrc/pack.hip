@@ -1,0 +1,151 @@
+// Weight pre-packing for the streaming GEMV (csrc/gemv.hip).
+//
+// HF stores a Linear weight as [out][in] row-major. An MFMA A-fragment load of gemv.hip
+// touches 16 rows x 64 bytes, i.e. 16 different DRAM pages per wave-instruction; measured,
+// that pattern streams ~20 % below a row-contiguous one on MI355X. The engine therefore keeps
+// a private copy of every matrix in the order the kernel consumes it: for each workgroup's
+// pair range, tile by tile, every 32-k step of a tile is ONE contiguous block
+//     [g = 0..3][row = 0..2*np-1] x 16 bytes      (np = pairs in the tile, <= 8)
+// so a wave-instruction reads 2*np*64 contiguous bytes and consecutive steps continue the same
+// stream: each wave walks one contiguous region of HBM. Rows of a tile are its pairs' first
+// rows, then their second rows (pair_rows). K is padded to a multiple of 32 with zeros, a
+// missing second row (odd vocabulary) is a zero row. The packed size is n_pairs*2*K32*2 bytes.
+
+#include "kernels.h"
+
+namespace sd {
+
+GemvGeom gemv_geometry(int n_pairs, int K) {
+  GemvGeom q{};
+  int grid = 256;  // one workgroup per CU
+  if (n_pairs < grid) grid = n_pairs;
+  q.ppw = (n_pairs + grid - 1) / grid;
+  q.grid = (n_pairs + q.ppw - 1) / q.ppw;
+  q.n_tiles = 1;
+  while (q.n_tiles * 8 < q.ppw) q.n_tiles <<= 1;
+  q.tile_pairs = (q.ppw + q.n_tiles - 1) / q.n_tiles;
+  int ksplit = 16 / (q.n_tiles < 16 ? q.n_tiles : 16);
+  while (ksplit > 1 && (K + ksplit * 32 - 1) / (ksplit * 32) < 2) ksplit >>= 1;  // >= 2 steps per slice
+  q.ksplit = ksplit;
+  q.kw = ((K + ksplit * 32 - 1) / (ksplit * 32)) * 32;
+  return q;
+}
+
+struct PackJob {
+  const uint16_t* src;
+  uint16_t* dst;
+  int N, K, n_pairs, epi, head_dim, ppw, tile_pairs;
+};
+
+__device__ __forceinline__ void pack_pair_rows(const PackJob& j, int p, int& r0, int& r1) {
+  if (j.epi == EPI_QKV_ROPE) {
+    const int half = j.head_dim >> 1;
+    const int h = p / half, i = p - h * half;
+    r0 = h * j.head_dim + i;
+    r1 = r0 + half;
+  } else if (j.epi == EPI_SWIGLU) {
+    r0 = p;
+    r1 = p + j.n_pairs;
+  } else {
+    r0 = 2 * p;
+    r1 = 2 * p + 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PackJob j) {
+  const int K32 = (j.K + 31) & ~31;
+  const int qn = K32 >> 3;  // 16-byte chunks per packed row
+  const size_t total = static_cast<size_t>(j.n_pairs) * 2 * qn;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * 256) {
+    const int q = static_cast<int>(i % qn);
+    const size_t t = i / qn;
+    const int second = static_cast<int>(t & 1);
+    const int p = static_cast<int>(t >> 1);
+    const int c = p / j.ppw;
+    const int p_lo = c * j.ppw;
+    const int p_hi = min(p_lo + j.ppw, j.n_pairs);
+    const int tile = (p - p_lo) / j.tile_pairs;
+    const int p0 = p_lo + tile * j.tile_pairs;
+    const int np = min(j.tile_pairs, p_hi - p0);
+    const int jp = p - p0;
+    const int S = q >> 2, g = q & 3;
+    const size_t dst_chunk = static_cast<size_t>(p0) * 2 * qn + static_cast<size_t>(S) * (2 * np * 4) + g * 2 * np + second * np + jp;
+    int r0, r1;
+    pack_pair_rows(j, p, r0, r1);
+    const int r = second ? r1 : r0;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < j.N && q * 8 + 8 <= j.K) v = *reinterpret_cast<const uint4*>(j.src + static_cast<size_t>(r) * j.K + q * 8);
+    *reinterpret_cast<uint4*>(j.dst + dst_chunk * 8) = v;
+  }
+}
+
+// matrices of the model in packing order: per layer qkv, out, up, down; then lm_head
+struct MatDesc {
+  const void* w;
+  int N, K, n_pairs, epi;
+};
+
+static void model_matrices(const sd_model_config& c, std::vector<MatDesc>& out) {
+  const bool llama = (c.arch == SD_ARCH_LLAMA);
+  const int d = c.d_model, Hq = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, ff = c.d_ff;
+  for (int l = 0; l < c.n_layers; ++l) {
+    const sd_layer_weights& w = c.layers[l];
+    out.push_back({w.wqkv, (Hq + 2 * Hkv) * D, d, (Hq + 2 * Hkv) * D / 2, EPI_QKV_ROPE});
+    out.push_back({w.wo, d, Hq * D, d / 2, EPI_RESID});
+    if (llama) out.push_back({w.w_up, 2 * ff, d, ff, EPI_SWIGLU});
+    else out.push_back({w.w_up, ff, d, ff / 2, EPI_GELU});
+    out.push_back({w.w_down, d, ff, d / 2, EPI_RESID});
+  }
+  out.push_back({c.lm_head, c.vocab, d, (c.vocab + 1) / 2, EPI_ARGMAX});
+}
+
+size_t packed_matrix_bytes(int n_pairs, int K) {
+  const size_t K32 = (static_cast<size_t>(K) + 31) & ~static_cast<size_t>(31);
+  return (static_cast<size_t>(n_pairs) * 2 * K32 * 2 + 255) & ~static_cast<size_t>(255);
+}
+
+// byte offset of matrix `index` (same order as model_matrices) inside the packed buffer
+size_t packed_offset(const sd_model_config& c, int index) {
+  std::vector<MatDesc> mats;
+  model_matrices(c, mats);
+  size_t off = 0;
+  for (int i = 0; i < index && i < static_cast<int>(mats.size()); ++i) off += packed_matrix_bytes(mats[i].n_pairs, mats[i].K);
+  return off;
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" size_t sd_packed_bytes(const sd_model_config* cfg) {
+  if (!cfg || !cfg->layers) return 0;
+  std::vector<MatDesc> mats;
+  model_matrices(*cfg, mats);
+  size_t n = 0;
+  for (const MatDesc& m : mats) n += packed_matrix_bytes(m.n_pairs, m.K);
+  return n;
+}
+
+extern "C" int sd_pack_weights(const sd_model_config* cfg, void* dst, size_t dst_bytes, void* stream) {
+  clear_error();
+  SD_REQUIRE(cfg && cfg->layers && dst, "pack_weights: NULL argument");
+  SD_REQUIRE(cfg->weight_dtype == SD_BF16, "pack_weights: only bf16 weights");
+  SD_REQUIRE(dst_bytes >= sd_packed_bytes(cfg), "pack_weights: destination too small");
+  SD_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 255) == 0, "pack_weights: destination must be 256-byte aligned");
+  std::vector<MatDesc> mats;
+  model_matrices(*cfg, mats);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* p = static_cast<char*>(dst);
+  for (const MatDesc& m : mats) {
+    SD_REQUIRE(m.w, "pack_weights: NULL matrix");
+    SD_REQUIRE(m.K % 8 == 0, "pack_weights: K=%d must be a multiple of 8", m.K);
+    const GemvGeom q = gemv_geometry(m.n_pairs, m.K);
+    PackJob j{static_cast<const uint16_t*>(m.w), reinterpret_cast<uint16_t*>(p), m.N, m.K, m.n_pairs, m.epi,
+              cfg->head_dim, q.ppw, q.tile_pairs};
+    hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, st, j);
+    SD_LAUNCH_CHECK();
+    p += packed_matrix_bytes(m.n_pairs, m.K);
+  }
+  return 0;
+}

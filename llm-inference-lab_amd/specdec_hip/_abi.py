@@ -57,6 +57,8 @@ SIGNATURES = {
          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_void_p],
     ),
     # ---- decoder forward + step loop ----
+    "sd_packed_bytes": (_c_size, [_c_void_p]),
+    "sd_pack_weights": (_c_int, [_c_void_p, _c_void_p, _c_size, _c_void_p]),
     "sd_model_create": (_c_int, [_c_void_p, _c_void_p]),
     "sd_model_destroy": (_c_int, [_c_void_p]),
     "sd_model_workspace_bytes": (_c_size, [_c_void_p]),

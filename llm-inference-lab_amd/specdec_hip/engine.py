@@ -8,6 +8,7 @@ streams. All arithmetic happens in csrc/.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -36,6 +37,7 @@ class _ModelConfig(ctypes.Structure):
         ("tok_emb", _vp), ("pos_emb", _vp), ("final_norm_w", _vp), ("final_norm_b", _vp),
         ("lm_head", _vp), ("rope_cos", _vp), ("rope_sin", _vp),
         ("layers", ctypes.POINTER(_LayerWeights)),
+        ("packed", _vp),
     ]
 
 
@@ -79,6 +81,18 @@ class HipModel:
             lm_head=_ptr(weights.lm_head), rope_cos=_ptr(weights.rope_cos), rope_sin=_ptr(weights.rope_sin),
             layers=self._layers,
         )
+        # the engine's packed copy of the Linear weights (one per ModelWeights, shared by every
+        # engine instance built over it)
+        packed = weights.meta.get("_packed")
+        if packed is None and not os.environ.get("SPECDEC_NO_PACK"):
+            nbytes = self.lib.sd_packed_bytes(ctypes.byref(mc))
+            with torch.cuda.device(dev):
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _abi.check(self.lib.sd_pack_weights(ctypes.byref(mc), packed.data_ptr(), nbytes,
+                                                    torch.cuda.current_stream(dev).cuda_stream), "sd_pack_weights")
+            weights.meta["_packed"] = packed
+        self._packed = packed
+        mc.packed = _ptr(packed)
         handle = _vp()
         _abi.check(self.lib.sd_model_create(ctypes.byref(mc), ctypes.byref(handle)), "sd_model_create")
         self.handle = handle
