@@ -41,6 +41,7 @@ namespace sd {
 constexpr int kGemvThreads = 1024;
 constexpr int kGemvWaves = kGemvThreads / kWave;  // 16 waves: 4 per SIMD
 constexpr int kBatch = 12;                        // loads in flight per lane
+constexpr int kPre = 8;                           // of which issued before the prologue
 
 constexpr int kXPad = 8;                          // bf16 elements of padding per staged x row
 
@@ -156,7 +157,8 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
 // ------------------------------------------------------------------------------
 template <int EPI>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
-                                         float y1, float& best_v, int& best_i) {
+                                         float y1, float& best_v, int& best_i, bool have_old = false,
+                                         uint32_t old_pre = 0) {
   const int b = t / a.M, m = t - b * a.M;
   if constexpr (EPI == EPI_QKV_ROPE) {
     if (a.bias) {
@@ -202,7 +204,7 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       y1 += bf16_bits_to_float(bs[r1]);
     }
     uint32_t* px = reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(a.out) + static_cast<size_t>(t) * a.out_stride + r0);
-    const uint32_t old = *px;
+    const uint32_t old = have_old ? old_pre : *px;  // prefetched at kernel entry when possible
     const float n0 = __uint_as_float(old << 16) + y0;
     const float n1 = __uint_as_float(old & 0xffff0000u) + y1;
     *px = static_cast<uint32_t>(float_to_bf16_bits(n0)) | (static_cast<uint32_t>(float_to_bf16_bits(n1)) << 16);
@@ -242,7 +244,10 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
 //   MASK = false: every K slice is whole 32-element steps inside the row (all Llama
 //   production shapes); MASK = true: any K % 8 == 0 (lanes past K load nothing).
 // ------------------------------------------------------------------------------
-template <int EPI, bool MASK>
+//   TT = compile-time bound on the token count (1, 2, 3, 5 or 9): the prologue's loads are
+//   unconditional straight-line code, which lets hipcc wait for them with a counted vmcnt
+//   while the weight batch issued after them is still in flight.
+template <int EPI, bool MASK, int TT>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -306,6 +311,19 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   };
 
   u32x4 buf[kBatch];
+  // first batch: unconditional (steps past the slice re-read its last step; never used). It is
+  // issued in two parts: kPre loads per wave before the prologue (64 KiB per CU: enough to keep
+  // HBM busy, few enough not to fill the CU's memory queue, which would stall the waves at
+  // issue and hold up the prologue's barriers), the rest right after it.
+  auto issue_first = [&](const uint16_t* ubase, int j0, int j1) {
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      if (j >= j0 && j < j1) {
+        const int s = (j < steps) ? j : steps - 1;
+        buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + static_cast<size_t>(s) * wstride + lane_off));
+      }
+    }
+  };
   auto issue = [&](const uint16_t* ubase, int s0) {
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
@@ -323,13 +341,118 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     if (a.debug_ts && tid == 0) a.debug_ts[static_cast<size_t>(blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
-  // start the weight stream before x is staged: HBM latency hides under the prologue
+
+  // ---- x staging, fast path (K <= 8192): thread `tid` owns the 16-byte chunk `tid` of every
+  // token row. Its loads (x rows, norm weights, the residual value of its epilogue item) are
+  // issued BEFORE the weight batch: vmcnt completes in order, so they return first and the
+  // whole prologue runs while the weights are still in flight.
+  const int nvec = K >> 3;
+  constexpr bool fast_stage = !MASK;  // the launcher sends K > 8192 to the MASK variant
+  const bool has_chunk = tid < nvec;
+  const int cidx = has_chunk ? tid : nvec - 1;  // clamp: every thread loads, owners store
+  u32x4 xr[TT];
+  u32x4 nw4 = {0u, 0u, 0u, 0u}, nb4 = {0u, 0u, 0u, 0u};
+  bool have_old = false;
+  uint32_t old_pre = 0;
+  if constexpr (fast_stage) {
+    const uint16_t* xin = static_cast<const uint16_t*>(a.x);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const int tt = (t < T) ? t : T - 1;
+      xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(tt) * a.x_stride + cidx * 8);
+    }
+    if (a.prologue != PRO_NONE) {  // kernel-uniform
+      nw4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + cidx * 8);
+      if (a.prologue == PRO_LAYERNORM) nb4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_b) + cidx * 8);
+    }
+    // residual epilogue: the old x value of this thread's (pair, token) item of round 0
+    if constexpr (EPI == EPI_RESID) {
+      const int ts = tid >> 7, jp = (tid >> 4) & 7, t = tid & 15;
+      const int p = p_lo + ts * tile_pairs + jp;
+      have_old = ts < tiles_per_round && ts < n_tiles && jp < tile_pairs && p < p_hi && t < T;
+      const int pc = have_old ? p : p_lo, tc = have_old ? t : 0;
+      old_pre = *reinterpret_cast<const uint32_t*>(static_cast<const uint16_t*>(a.out) + static_cast<size_t>(tc) * a.out_stride + 2 * pc);
+    }
+  }
+
+  // start the weight stream: its HBM latency hides under the rest of the prologue
   const bool first_valid = tslot < n_tiles;
   const uint16_t* wrow0 = tile_base(first_valid ? tslot : 0);
-  if (first_valid) issue(wrow0, 0);
+  if constexpr (MASK) {
+    if (first_valid) issue(wrow0, 0);
+  } else {
+    issue_first(wrow0, 0, kPre);  // waves without a tile re-read tile 0's first steps (L2 hits)
+  }
   stamp(1);
 
-  stage_x(a, xs, KP, red);
+  if constexpr (!fast_stage) {
+    stage_x(a, xs, KP, red);
+  } else if (a.prologue == PRO_NONE) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+      if (t < T && has_chunk) *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + tid * 8) = xr[t];
+    __syncthreads();
+  } else {
+    // per-row sum / sum of squares: own chunk -> wave -> LDS -> every thread
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (t < T) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(xr[t][j] << 16), hi = __uint_as_float(xr[t][j] & 0xffff0000u);
+          s1 += lo + hi;
+          s2 += lo * lo + hi * hi;
+        }
+        if (!has_chunk) { s1 = 0.f; s2 = 0.f; }  // clamped (duplicate) loads do not count
+        s1 = wave_reduce_sum(s1);
+        s2 = wave_reduce_sum(s2);
+        if (lane == 0) {
+          red[(t * kGemvWaves + wave) * 2 + 0] = s1;
+          red[(t * kGemvWaves + wave) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    const float invK = 1.0f / static_cast<float>(K);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (t < T) {
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGemvWaves; ++w) {
+          sum += red[(t * kGemvWaves + w) * 2 + 0];
+          sq += red[(t * kGemvWaves + w) * 2 + 1];
+        }
+        u32x4 o;
+        if (a.prologue == PRO_RMSNORM) {
+          // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
+          const float rs = rsqrtf(sq * invK + a.norm_eps);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x0 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xr[t][j] << 16) * rs));
+            const float x1 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xr[t][j] & 0xffff0000u) * rs));
+            o[j] = static_cast<uint32_t>(float_to_bf16_bits(x0 * __uint_as_float(nw4[j] << 16))) |
+                   (static_cast<uint32_t>(float_to_bf16_bits(x1 * __uint_as_float(nw4[j] & 0xffff0000u))) << 16);
+          }
+        } else {
+          // GPT-2 LayerNorm in fp32, rounded once
+          const float mean = sum * invK;
+          const float rs = rsqrtf(fmaxf(sq * invK - mean * mean, 0.f) + a.norm_eps);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float y0 = (__uint_as_float(xr[t][j] << 16) - mean) * rs * __uint_as_float(nw4[j] << 16) + __uint_as_float(nb4[j] << 16);
+            const float y1 = (__uint_as_float(xr[t][j] & 0xffff0000u) - mean) * rs * __uint_as_float(nw4[j] & 0xffff0000u) +
+                             __uint_as_float(nb4[j] & 0xffff0000u);
+            o[j] = static_cast<uint32_t>(float_to_bf16_bits(y0)) | (static_cast<uint32_t>(float_to_bf16_bits(y1)) << 16);
+          }
+        }
+        if (has_chunk) *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + tid * 8) = o;
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (!MASK) issue_first(wrow0, kPre, kBatch);
   stamp(2);
 
   float best_v = -INFINITY;
@@ -383,7 +506,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         }
         int r0, r1;
         pair_rows<EPI>(a, p, r0, r1);
-        epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i);
+        epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i, have_old && r == 0 && it == tid, old_pre);
       }
     }
     if (r == 0) stamp(5);
@@ -429,23 +552,28 @@ int gemv_grid(const GemvArgs& a, int* ppw_out) {
   return q.grid;
 }
 
-template <int EPI, bool MASK>
+template <int EPI, bool MASK, int TT>
 static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into once per kernel
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK>),
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT>), dim3(grid), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
 template <int EPI>
 static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
-  return mask ? launch_one<EPI, true>(a, grid, smem, st) : launch_one<EPI, false>(a, grid, smem, st);
+  if (mask) return launch_one<EPI, true, kGemvMaxT>(a, grid, smem, st);  // generic shapes: one variant
+  if (a.T <= 1) return launch_one<EPI, false, 1>(a, grid, smem, st);
+  if (a.T <= 2) return launch_one<EPI, false, 2>(a, grid, smem, st);
+  if (a.T <= 3) return launch_one<EPI, false, 3>(a, grid, smem, st);
+  if (a.T <= 5) return launch_one<EPI, false, 5>(a, grid, smem, st);
+  return launch_one<EPI, false, kGemvMaxT>(a, grid, smem, st);
 }
 
 int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
@@ -461,7 +589,9 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
   a.tile_pairs = q.tile_pairs;
   a.ksplit = q.ksplit;
   a.kw = q.kw;
-  const bool mask = (a.kw * ksplit != a.K);
+  // MASK variant: slices that are not whole 32-k steps, or rows longer than the one-chunk-per-
+  // thread register staging covers
+  const bool mask = (a.kw * ksplit != a.K) || (a.K / 8 > kGemvThreads);
   size_t smem = gemv_smem(a.T, a.K, false);
   a.alias_part = 0;
   if (smem > kLdsLimit && n_tiles <= kGemvWaves / ksplit) {  // single round: partials may alias x
