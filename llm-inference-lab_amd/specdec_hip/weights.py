@@ -357,3 +357,44 @@ def synthetic_llama(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.b
         meta={"synthetic": True, "seed": seed, "layer_gain": layer_gain, "flip_fraction": flip_fraction,
               "successor": (successor_mult, successor_add)},
     )
+
+
+def synthetic_gpt2(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.bfloat16, layer_gain: float = 0.05,
+                   successor_mult: int = 7919, successor_add: int = 1, embed_from: Optional[ModelWeights] = None,
+                   flip_fraction: float = 0.0, flip_seed: int = 99) -> ModelWeights:
+    """GPT-2-shaped counterpart of `synthetic_llama` (LayerNorm with biases, learned positions,
+    biased linears, gelu_new MLP): the same successor construction on untied in/out tables."""
+    assert cfg.arch == ARCH_GPT2
+    gen = torch.Generator(device=device).manual_seed(seed)
+    d, ff, V = cfg.d_model, cfg.d_ff, cfg.vocab
+    if embed_from is not None:
+        e_out = embed_from.lm_head[:, :d].contiguous().to(device=device, dtype=dtype)
+    else:
+        e_out = _randn((V, d), 1.0, gen, device, dtype)
+    tok = torch.arange(V, device=device, dtype=torch.int64)
+    succ = (tok * successor_mult + successor_add) % V
+    if flip_fraction > 0.0:
+        fg = torch.Generator(device="cpu").manual_seed(flip_seed)
+        flip = (torch.rand(V, generator=fg) < flip_fraction).to(device)
+        succ = torch.where(flip, (succ * 31 + 17) % V, succ)
+    e_in = e_out.index_select(0, succ).contiguous()
+
+    def vec(std):
+        return _randn((d,), std, gen, device, dtype)
+
+    layers = []
+    for _ in range(cfg.n_layers):
+        layers.append(LayerWeights(
+            attn_norm_w=(1.0 + vec(0.02).float()).to(dtype), attn_norm_b=vec(0.02),
+            wqkv=_randn((3 * d, d), 1.0 / math.sqrt(d), gen, device, dtype), bqkv=_randn((3 * d,), 0.02, gen, device, dtype),
+            wo=_randn((d, d), layer_gain / math.sqrt(d), gen, device, dtype), bo=vec(0.01),
+            mlp_norm_w=(1.0 + vec(0.02).float()).to(dtype), mlp_norm_b=vec(0.02),
+            w_up=_randn((ff, d), 1.0 / math.sqrt(d), gen, device, dtype), b_up=_randn((ff,), 0.02, gen, device, dtype),
+            w_down=_randn((d, ff), layer_gain / math.sqrt(ff), gen, device, dtype), b_down=vec(0.01),
+        ))
+    return ModelWeights(
+        cfg, e_in, e_out, (1.0 + vec(0.02).float()).to(dtype), layers, final_norm_b=vec(0.02),
+        pos_emb=_randn((cfg.max_pos, d), 0.05, gen, device, dtype),
+        meta={"synthetic": True, "seed": seed, "layer_gain": layer_gain, "flip_fraction": flip_fraction,
+              "successor": (successor_mult, successor_add)},
+    )

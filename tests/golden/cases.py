@@ -143,3 +143,18 @@ def g8_pairs(dtype=torch.float32):
 
 def weights_checksum(mw) -> float:
     return float(sum(checksum(t) for name, t in mw.tensors() if not name.startswith("rope_")))
+
+
+def build_policy_case(K, V, seed):
+    """draft logits, base logits [1,K,V] fp32 and token ids [1,K] for the policy goldens: the
+    base agrees with the draft on a random prefix, so every policy sees accepts and rejects."""
+    rng = np.random.default_rng(seed)
+    dl = torch.from_numpy(rng.standard_normal((1, K, V)).astype(np.float32)) * 2
+    bl = torch.from_numpy(rng.standard_normal((1, K, V)).astype(np.float32)) * 2
+    d_ids = dl.argmax(-1)
+    agree = int(rng.integers(0, K + 1))
+    for k in range(K):
+        if k < agree:
+            bl[0, k, int(d_ids[0, k])] = 9.0 + rng.random()
+    b_ids = bl.argmax(-1)
+    return dl, bl, d_ids, b_ids

@@ -208,6 +208,65 @@ def gen_pipeline():
         json.dump(out, f, indent=1, default=str)
 
 
+def gen_hostlogic():
+    """G3-G6: the reference's host-side pieces on seeded inputs (policies, bonus-token
+    filtering, controllers, sequence utils, token validation)."""
+    from specdec.core.pipeline import sample_bonus_token_from_logits
+    from specdec.core.sequence_utils import create_position_ids, pad_sequences
+    from specdec.policies.controllers import create_controller
+    from specdec.policies.policies import create_policy
+    from specdec.utils.token_validation import validate_and_clamp_tokens
+
+    rng = np.random.default_rng(2024)
+    out = {"policies": [], "controllers": [], "bonus": [], "sequences": [], "clamp": []}
+    for case in range(24):
+        K, V = int(rng.integers(1, 7)), int(rng.integers(20, 400))
+        seed = 9000 + case
+        dl, bl, d_ids, b_ids = cases.build_policy_case(K, V, seed)
+        row = {"seed": seed, "K": K, "V": V}
+        for name, kw in (("longest_prefix", {}), ("conf_threshold", {"tau": 0.3}), ("topk_agree", {"k": 3}),
+                         ("typical", {"p": 0.2})):
+            pol = create_policy(name, **kw)
+            a_logits, _ = pol.accept_tokens(d_ids, b_ids, dl, bl)
+            a_ids, _ = pol.accept_tokens(d_ids, b_ids)  # no logits: id comparison / fallback
+            row[name] = [int(a_logits), int(a_ids)]
+        out["policies"].append(row)
+    for case in range(6):
+        params = {"initial_k": int(rng.integers(1, 6)), "min_k": 1, "max_k": int(rng.integers(4, 9)),
+                  "step_size": int(rng.integers(1, 3)), "window_size": int(rng.integers(4, 12)),
+                  "target_acceptance_rate": float(rng.uniform(0.3, 0.8))}
+        ctl = create_controller("adaptive", **params)
+        rates = rng.uniform(0, 1, size=40).round(3).tolist()
+        ks = [ctl.get_k(i, {"acceptance_rate": r} if i % 7 else {}) for i, r in enumerate(rates)]
+        out["controllers"].append({"params": params, "rates": rates, "ks": [int(k) for k in ks],
+                                   "info_recent": ctl.get_info()["recent_acceptance_rate"]})
+    for case in range(12):
+        V = int(rng.integers(30, 300))
+        seed = 9500 + case
+        logits = torch.from_numpy(np.random.default_rng(seed).standard_normal(V).astype(np.float32)) * 3
+        top_k = int(rng.integers(0, 20))
+        top_p = float(rng.choice([1.0, 0.9, 0.5, 0.2]))
+        temp = float(rng.choice([1.0, 0.7, 0.1]))
+        tok = sample_bonus_token_from_logits(logits, temp, False, top_p=top_p, top_k=top_k if top_k else None, vocab_size=V)
+        out["bonus"].append({"seed": seed, "V": V, "top_k": top_k, "top_p": top_p, "temperature": temp,
+                             "greedy_token": int(tok[0])})
+    for case in range(8):
+        n = int(rng.integers(1, 6))
+        lens = [int(x) for x in rng.integers(1, 9, size=n)]
+        seqs = [torch.from_numpy(rng.integers(1, 50, size=L, dtype=np.int64)) for L in lens]
+        batch, mask, ol = pad_sequences(seqs, 0, torch.device("cpu"))
+        pos = create_position_ids(ol, batch.shape[1], torch.device("cpu"))
+        out["sequences"].append({"seqs": [s_.tolist() for s_ in seqs], "batch": batch.tolist(), "mask": mask.tolist(),
+                                 "lengths": ol, "position_ids": pos.tolist()})
+    for case in range(6):
+        V = int(rng.integers(10, 100))
+        ids = torch.from_numpy(rng.integers(-5, V + 5, size=(2, 7), dtype=np.int64))
+        out["clamp"].append({"V": V, "ids": ids.tolist(), "out": validate_and_clamp_tokens(ids, V, "g").tolist()})
+    with open(os.path.join(HERE, "hostlogic_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("hostlogic goldens:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["kernels"]
@@ -217,3 +276,5 @@ if __name__ == "__main__":
         gen_hf()
     if "pipeline" in which:
         gen_pipeline()
+    if "hostlogic" in which:
+        gen_hostlogic()
