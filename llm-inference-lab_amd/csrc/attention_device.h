@@ -1,0 +1,190 @@
+// Device-side body of the K-token attention (shared by attention.hip and the fused
+// attention + out-projection variant of gemv.hip). See attention.hip for the design notes.
+#pragma once
+
+#include "kernels.h"
+
+namespace sd {
+
+constexpr int kAttnThreads = 256;
+constexpr int kAttnWaves = 4;
+constexpr int kAttnRows = 16;    // query rows per workgroup (MFMA tile)
+constexpr int kAttnBlock = 32;   // keys per block
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return static_cast<uint32_t>(float_to_bf16_bits(lo)) | (static_cast<uint32_t>(float_to_bf16_bits(hi)) << 16);
+}
+
+// One (batch row, kv head, 16-query-row tile). Called by a whole workgroup; only the threads
+// with `active` (the first 256 = 4 waves) compute, every thread takes the one barrier.
+template <int D>
+__device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b, int tile, unsigned char* smem,
+                                               bool active) {
+  constexpr int NKS = D / 32;  // k-steps of the QK^T contraction
+  constexpr int NDT = D / 16;  // 16-wide tiles of the output channels
+  const int G = a.n_q_heads / a.n_kv_heads, M = a.M;
+  const int R = G * M;
+  const int r_base = tile * kAttnRows;
+  const int rows = min(kAttnRows, R - r_base);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+
+  float* o_s = reinterpret_cast<float*>(smem);            // [waves][16][D]
+  float* m_s = o_s + kAttnWaves * kAttnRows * D;          // [waves][16]
+  float* l_s = m_s + kAttnWaves * kAttnRows;              // [waves][16]
+
+  const int pos0 = a.pos_base[b] + a.pos_off;             // position of query m = 0
+  const int n_keys = max(0, min(pos0 + M, a.l_max));      // keys visible to the last query
+  const int n_blocks = (n_keys + kAttnBlock - 1) / kAttnBlock;
+
+  // ---- Q fragments: lane (g, n) holds Q[row n][32 s + 8 g .. +8] for s < NKS -------
+  const int qstride = a.n_q_heads * D;
+  u32x4 qf[NKS];
+  int my_m = 0;  // query position index of row n (for the causal mask)
+  {
+    const uint16_t* q = static_cast<const uint16_t*>(a.q);
+    const bool valid = n < rows;
+    const int rr = r_base + (valid ? n : 0);
+    const int gh = rr / M, m = rr - gh * M;
+    my_m = m;
+    const uint16_t* qrow = q + static_cast<size_t>(b * M + m) * qstride + (kvh * G + gh) * D + g * 8;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      if (valid) qf[s] = *reinterpret_cast<const u32x4*>(qrow + s * 32);
+      else qf[s] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+
+  const uint16_t* kc = static_cast<const uint16_t*>(a.k_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max * D;
+  const uint16_t* vt = static_cast<const uint16_t*>(a.v_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * D * a.l_max;
+
+  f32x4_t oacc[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;  // for query row n (replicated over g)
+
+  const int my_limit = pos0 + my_m;  // last key this lane's query may see
+
+  for (int blk = active ? wave : n_blocks; blk < n_blocks; blk += kAttnWaves) {
+    const int key0 = blk * kAttnBlock;
+    // ---- issue every load of the block -------------------------------------------
+    // S^T tile u (u = 0,1): MFMA row i (= lane n) is key  key0 + 8*(i>>2) + 4*u + (i&3)
+    u32x4 kf[2][NKS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int key = key0 + 8 * (n >> 2) + 4 * u + (n & 3);
+      if (key >= a.l_max) key = a.l_max - 1;  // stay inside the cache; masked below
+      const uint16_t* krow = kc + static_cast<size_t>(key) * D + g * 8;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) kf[u][s] = *reinterpret_cast<const u32x4*>(krow + s * 32);
+    }
+    // V^T fragment of channel tile i: lane (g, n) holds V^T[16 i + n][key0 + 8 g .. +8]
+    u32x4 vf[NDT];
+    {
+      int kofs = key0 + 8 * g;
+      if (kofs + 8 > a.l_max) kofs = a.l_max - 8;  // l_max % 8 == 0 (checked by the host)
+      const uint16_t* vrow = vt + static_cast<size_t>(n) * a.l_max + kofs;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) vf[i] = *reinterpret_cast<const u32x4*>(vrow + static_cast<size_t>(16 * i) * a.l_max);
+    }
+    // ---- S^T = K Q^T -----------------------------------------------------------------
+    f32x4_t st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[u][s]),
+                                                        __builtin_bit_cast(bf16x8_t, qf[s]), st[u], 0, 0, 0);
+    }
+    // lane (g, n) now holds, for query row n, the scores of keys key0 + 8g + (4u + r)
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 8 * g + 4 * u + r;
+        const bool vis = (key <= my_limit) && (key < n_keys);
+        const float v = vis ? st[u][r] * a.scale : -INFINITY;
+        sc[4 * u + r] = v;
+        mx = fmaxf(mx, v);
+      }
+    // row max / sum across the 4 lane groups that share n
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float alpha = 1.f, psum = 0.f;
+    float p[8];
+    if (m_new > -INFINITY) {
+      alpha = (m_run > -INFINITY) ? __expf(m_run - m_new) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[j] = (sc[j] > -INFINITY) ? __expf(sc[j] - m_new) : 0.f;
+        psum += p[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] = 0.f;
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // P as the A operand: lane (g, n = q) holds P[q][key0 + 8g + j], j = 0..7
+    const u32x4 pf = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+    // rescale O: lane (g, n = d) holds O[q = 4g + r][d]; alpha of row q lives in lane q
+    float al[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) al[r] = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[i][r] *= al[r];
+      oacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf),
+                                                        __builtin_bit_cast(bf16x8_t, vf[i]), oacc[i], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the 4 waves ----------------------------------------------------------------
+  if (active) {
+  if (g == 0) {
+    m_s[wave * kAttnRows + n] = m_run;
+    l_s[wave * kAttnRows + n] = l_run;
+  }
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o_s[(wave * kAttnRows + 4 * g + r) * D + 16 * i + n] = oacc[i][r];
+  }
+  __syncthreads();
+  uint16_t* out = static_cast<uint16_t*>(a.out);
+  for (int i = active ? tid : rows * D; i < rows * D; i += kAttnThreads) {
+    const int r = i / D, d = i - r * D;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kAttnWaves; ++w) mm = fmaxf(mm, m_s[w * kAttnRows + r]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < kAttnWaves; ++w) {
+      const float mw = m_s[w * kAttnRows + r];
+      const float f = (mw > -INFINITY) ? __expf(mw - mm) : 0.f;
+      num += f * o_s[(w * kAttnRows + r) * D + d];
+      den += f * l_s[w * kAttnRows + r];
+    }
+    const float v = (den > 0.f) ? num / den : 0.f;
+    const int rr = r_base + r, gh = rr / M, m = rr - gh * M;
+    out[static_cast<size_t>(b * M + m) * qstride + (kvh * G + gh) * D + d] = float_to_bf16_bits(v);
+  }
+}
+
+
+inline size_t attention_smem_bytes(int D) {
+  return sizeof(float) * (static_cast<size_t>(kAttnWaves) * kAttnRows * D + 2 * kAttnWaves * kAttnRows);
+}
+
+}  // namespace sd
