@@ -209,6 +209,16 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_mfma_kernel<EPI_SWIGLU> (target norm+gate/up+SwiGLU)",
                            "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK_BPS,
                            "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": usec}
+        # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
+        # runs, FETCH_SIZE x2 on gfx950): counters cannot be read from inside this process, so the
+        # figure comes from the committed summary of the same command (profiles/summarize.py)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+        if os.path.exists(pmc) and min(B * (K + 1), 9) == 5:
+            with open(pmc) as f:
+                t = json.load(f).get("gemv_mfma_kernel<2, false, 5>")
+            if t:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc passes of bench.py)"
         others = {}
         for name, which, T in (("target_lm_head", tm.PROBE_LM_HEAD, min(B * (K + 1), 9)),
                                ("target_down", tm.PROBE_DOWN, min(B * (K + 1), 9)),

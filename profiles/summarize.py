@@ -1,5 +1,5 @@
 """Summarise rocprofv3 output of a bench.py run (kernel-trace stats + PMC passes) into a
-small table. Usage: python profiles/summarize.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> > profiles/<name>.md
+small table. Usage: python profiles/summarize.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> [traffic.json] > profiles/<name>.md
 FETCH_SIZE is in KiB and, on gfx950, counts exactly half of a 16-B/lane coalesced stream
 (MI355X_MICROARCH.md §HBM): the corrected figure doubles it. WRITE_SIZE is exact."""
 
@@ -17,12 +17,12 @@ def short(name):
 
 
 def load_trace(d):
-    f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+    f = (glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
     return [r for r in csv.DictReader(open(f)) if "sd::" in r["Kernel_Name"]]
 
 
 def load_pmc(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     return [r for r in csv.DictReader(open(f)) if "sd::" in r["Kernel_Name"]]
 
 
@@ -41,6 +41,18 @@ def main():
             key = (short(r["Kernel_Name"]), r["LDS_Block_Size"])
             pmc.setdefault((key, cname), []).append(float(r["Counter_Value"]))
     total = sum(sum(v) for v in agg.values())
+    if len(sys.argv) > 4:   # machine-readable per-launch HBM traffic (bench.py's roofline.traffic)
+        import json
+
+        tr = {}
+        for key in agg:
+            f, w = pmc.get((key, "FETCH_SIZE")), pmc.get((key, "WRITE_SIZE"))
+            if f and w:
+                rd, wr = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
+                tr[key[0].split("(")[0]] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_x2_corrected": rd, "write_bytes": wr,
+                                            "launches_counted": len(f)}
+        with open(sys.argv[4], "w") as fo:
+            json.dump(tr, fo, indent=1)
     print("| kernel | LDS B | launches | avg us | total ms | % | FETCH KiB/launch (raw) | HBM read MB/launch (x2 corrected) | WRITE KiB/launch |")
     print("|---|---|---|---|---|---|---|---|---|")
     for key, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):

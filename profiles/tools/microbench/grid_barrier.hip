@@ -1,0 +1,94 @@
+// How much does a device-wide barrier cost on MI355X when every CU holds one 1024-thread
+// workgroup (the GEMV shape)? Compared against the floor of back-to-back kernel launches
+// (~4.5 us per dependent launch in the bench trace). Build: hipcc --offload-arch=gfx950 -O3
+// grid_barrier.hip -o grid_barrier ; run: ./grid_barrier
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// monotonic counter barrier: phase p completes when counter >= (p+1)*nwg
+template <int MODE>
+__global__ __launch_bounds__(1024) void barrier_kernel(unsigned* counter, float* data, int phases, int payload) {
+  const unsigned nwg = gridDim.x;
+  float acc = 0.f;
+  for (int p = 0; p < phases; ++p) {
+    // a little "work": each WG writes a value every other WG reads after the barrier
+    if (payload && threadIdx.x < 64) data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc + p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (MODE == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * nwg;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      } else {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * nwg;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+    if (payload) {
+      const unsigned src = (blockIdx.x + 97) % nwg;   // another WG's (likely another XCD's) data
+      if (threadIdx.x < 64) acc += data[(p & 1) * nwg * 64 + src * 64 + threadIdx.x];
+    }
+  }
+  if (payload && threadIdx.x < 64) data[2 * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+__global__ void empty_kernel(float* d) { if (d == nullptr) *d = 0; }
+
+int main() {
+  int dev = 0; CK(hipSetDevice(dev));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, dev));
+  const int ncu = prop.multiProcessorCount;
+  printf("device %s, %d CUs\n", prop.name, ncu);
+  unsigned* counter; float* data;
+  CK(hipMalloc(&counter, 4)); CK(hipMalloc(&data, 3 * ncu * 64 * 4));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int phases = 2000;
+  for (int mode = 0; mode < 2; ++mode)
+    for (int payload = 0; payload < 2; ++payload)
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemsetAsync(counter, 0, 4, st));
+        CK(hipMemsetAsync(data, 0, 3 * ncu * 64 * 4, st));
+        CK(hipEventRecord(e0, st));
+        void* args[] = {&counter, &data, (void*)&phases, &payload};
+        // cooperative launch: co-residency of all workgroups is guaranteed or the launch fails
+        if (mode == 0) CK(hipLaunchCooperativeKernel((void*)barrier_kernel<0>, dim3(ncu), dim3(1024), args, 0, st));
+        else CK(hipLaunchCooperativeKernel((void*)barrier_kernel<1>, dim3(ncu), dim3(1024), args, 0, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("mode %d (%s) payload %d: %.3f us per barrier\n", mode, mode ? "sleep" : "spin", payload, ms * 1e3 / phases);
+        if (payload && rep) {
+          std::vector<float> h(ncu * 64);
+          CK(hipMemcpy(h.data(), data + 2 * ncu * 64, ncu * 64 * 4, hipMemcpyDeviceToHost));
+          // every phase p adds (acc_src + p); all WGs symmetric -> acc identical everywhere
+          bool same = true; for (int i = 1; i < ncu * 64; ++i) same &= (h[i] == h[0]);
+          printf("   payload check: %s (acc=%g)\n", same ? "consistent" : "MISMATCH", h[0]);
+        }
+      }
+  // floor of dependent kernel launches in a captured graph
+  {
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < 500; ++i) hipLaunchKernelGGL(empty_kernel, dim3(ncu), dim3(1024), 0, st, data);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0, st));
+      CK(hipGraphLaunch(ge, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("graph of 500 empty 1024-thread x %d-WG kernels: %.3f us per launch\n", ncu, ms * 1e3 / 500);
+    }
+  }
+  return 0;
+}
