@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--flip", type=float, default=0.2, help="fraction of tokens whose draft successor differs")
     ap.add_argument("--cpu-baseline-steps", type=int, default=6, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--do-sample", action="store_true",
+                    help="sampled bonus token (T=0.7, top_k=50, top_p=0.9: the reference's default sampler) instead of greedy; "
+                         "not the headline configuration (SPECDEC_DETERMINISTIC is greedy), no CPU parity leg")
     return ap.parse_args()
 
 
@@ -145,7 +148,11 @@ def main():
     K, B = args.k, args.batch
     prompts = prompts_for(rank, B, tgt.config.vocab)
     total_steps = args.warmup + args.steps
-    sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1, emit_mode=HipSpecDec.EMIT_BONUS)
+    sampling = {"temperature": 0.7, "top_k": 50, "top_p": 0.9, "seed": 1234} if args.do_sample else None
+    if sampling:
+        args.cpu_baseline_steps = 0
+    sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1, emit_mode=HipSpecDec.EMIT_BONUS,
+                              sampling=sampling)
 
     def barrier():
         if dist is not None:
@@ -188,7 +195,7 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, greedy, "
+        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}, "
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},

@@ -75,6 +75,23 @@ int sd_verify_prefix(const void* logits, int logits_dtype,
                      void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Sampled token from logits rows: temperature -> top-k -> top-p -> one categorical draw.
+ * Replaces sample_bonus_token_from_logits (src/specdec/core/pipeline.py:48-147) for
+ * do_sample=True. Entry b reads row  b*rows_per_b + (pos ? pos[b] : 0)  of `logits`
+ * ([rows][V], row_stride elements apart, f32 / bf16 / f16) and writes out_ids[b]; entries with
+ * active[b] == 0 (if given) are skipped. Order among equal logits: value descending, index
+ * ascending. The nucleus cut drops a token when the inclusive cumulative probability (descending
+ * order, inside the top-k) exceeds top_p; the first token is always kept. The draw is one
+ * Philox4x32-10 value with key = seed and counter = (draw index, stream, 0, tag), inverted through
+ * the cumulative weights; draw index = draw_counters[b] (then incremented) or draw0 when
+ * draw_counters is NULL; stream = stream_id[b] or b. top_k in 1..1024; top_k <= 0 with
+ * top_p >= 1 draws from the whole row (Gumbel-max, one Philox value per element); top_k <= 0
+ * with top_p < 1 is refused. Asynchronous on `stream`, no allocation, graph-capturable. */
+int sd_sample_token(const void* logits, int logits_dtype, int64_t row_stride, int B, int V,
+                    const int32_t* pos, int rows_per_b, const int32_t* active, float temperature,
+                    int top_k, float top_p, uint64_t seed, uint32_t* draw_counters, uint32_t draw0,
+                    const int32_t* stream_id, int32_t* out_ids, void* stream);
+
 /* ------------------------------------------------------------------------
  * kv_append (in place) — the KV-append path
  *   reference contract: kv_append_ref, src/kernels/reference.py:59-93
@@ -250,6 +267,18 @@ int sd_specdec_destroy(sd_specdec* s);
  * [0, seq_len-2] or more of the draft. Asynchronous on `stream`. */
 int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_tok, int last_tok,
                        int active, void* stream);
+
+/* Sampled bonus token inside the step (generate_batch with do_sample=True: the reference
+ * samples ONLY the token after the accepted prefix, pipeline.py:3140-3160 and :3351-3361;
+ * drafting and verification stay greedy, :2400/:2645). With enable=1 the verify forward stores
+ * its logits ([B][K+1][V] bf16 in logits_buf, caller-owned), and between the accept scan and the
+ * state advance one sampler launch draws row b's token from the logits of position
+ * accept_len[b] (sd_sample_token semantics; draw index = draw_counters[b], incremented per
+ * sampled step; Philox stream = stream_ids[b] or b). enable=0 returns to the greedy step.
+ * Either call drops the captured graph (it is re-captured on the next step). */
+int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperature, int top_k, float top_p,
+                            uint64_t seed, void* logits_buf, size_t logits_bytes,
+                            uint32_t* draw_counters, const int32_t* stream_ids);
 
 /* Enqueue ONE draft-then-verify step for all rows: K draft forwards (the first over
  * (prev,last), the rest over one token), one verify forward over (last,d_1..d_K),

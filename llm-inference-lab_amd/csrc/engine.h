@@ -22,9 +22,16 @@ struct SpecState {
   int32_t* accept_len;  // [B]
   int32_t* n_new;       // [B]
   int32_t* new_tok;     // [B][K+1] emitted tokens, -1 padded
+  int32_t* sampled;     // [B]   sampled token for position accept_len (sampling mode), else unused
 };
 
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);
-int launch_accept(const SpecState& s, int mode, hipStream_t st);
+int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st);
+int launch_accept_len(const SpecState& s, hipStream_t st);
+
+// csrc/sample.hip
+struct SampleArgs;
+int launch_sample_step(const SpecState& s, const void* logits, int V, float temperature, int top_k, float top_p,
+                       uint64_t seed, uint32_t* draw, const int32_t* stream_id, hipStream_t st);
 
 }  // namespace sd

@@ -466,6 +466,14 @@ struct sd_specdec {
   hipGraphExec_t exec = nullptr;
   hipStream_t graph_st_t = nullptr, graph_st_d = nullptr;
   long steps = 0;
+  // sampled bonus token (sd_specdec_set_sampling); all buffers are caller-owned
+  int sample = 0;
+  float temperature = 1.0f, top_p = 1.0f;
+  int top_k = 0;
+  uint64_t seed = 0;
+  void* logits = nullptr;          // [B][K+1][V] bf16
+  uint32_t* draw = nullptr;        // [B]
+  const int32_t* stream_id = nullptr;
 };
 
 namespace sd {
@@ -508,9 +516,16 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   }
   // verify: one forward over (last, d_1..d_K)
   if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, K + 1, s->st.target_ids,
-                             K + 1, nullptr, SD_BF16, 0, st_t))
+                             K + 1, s->sample ? s->logits : nullptr, SD_BF16, 0, st_t))
     return rc;
-  if (int rc = launch_accept(s->st, s->mode, st_t)) return rc;
+  if (s->sample) {
+    // accept length -> draw the token after the accepted prefix from the stored logits of that position
+    if (int rc = launch_accept_len(s->st, st_t)) return rc;
+    if (int rc = launch_sample_step(s->st, s->logits, s->target->cfg.vocab, s->temperature, s->top_k, s->top_p, s->seed,
+                                    s->draw, s->stream_id, st_t))
+      return rc;
+  }
+  if (int rc = launch_accept(s->st, s->mode, s->sample, st_t)) return rc;
   hipLaunchKernelGGL(pack_record_kernel, dim3(B), dim3(kWave), 0, st_t, s->st, s->dev_record, s->rec);
   SD_LAUNCH_CHECK();
   SD_HIP_CHECK(hipMemcpyAsync(s->host_record, s->dev_record, sizeof(int32_t) * B * s->rec, hipMemcpyDeviceToHost, st_t));
@@ -537,7 +552,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   s->K = K;
   s->mode = emit_mode;
   s->rec = 5 + 3 * K;
-  const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1));
+  const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1) + 1);
   const size_t n_total = n_state + static_cast<size_t>(B) * s->rec;
   hipError_t e = hipMalloc(&s->dev_block, n_total * sizeof(int32_t));
   if (e != hipSuccess) {
@@ -560,6 +575,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   st.accept_len = p; p += B;
   st.n_new = p; p += B;
   st.new_tok = p; p += static_cast<size_t>(B) * (K + 1);
+  st.sampled = p; p += B;
   s->dev_record = p;
   if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * B * s->rec, hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * 8, hipHostMallocDefault) != hipSuccess ||
@@ -603,6 +619,39 @@ extern "C" int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_to
   SD_HIP_CHECK(hipMemcpyAsync(s->st.active + b, h + 1, 4, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.tok2 + 2 * b, h + 2, 8, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.verify_tok + static_cast<size_t>(b) * (s->K + 1), h + 3, 4, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+extern "C" int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperature, int top_k, float top_p,
+                                       uint64_t seed, void* logits_buf, size_t logits_bytes, uint32_t* draw_counters,
+                                       const int32_t* stream_ids) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_set_sampling: NULL");
+  if (s->exec) {  // the captured step holds the sampling launches and their parameters
+    (void)hipGraphExecDestroy(s->exec);
+    (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+  }
+  if (!enable) {
+    s->sample = 0;
+    return 0;
+  }
+  SD_REQUIRE(s->mode == SD_EMIT_BONUS, "specdec_set_sampling: only the bonus-token emit mode (generate_batch) samples");
+  SD_REQUIRE(logits_buf && draw_counters, "specdec_set_sampling: NULL logits buffer / draw counters");
+  const size_t need = static_cast<size_t>(s->B) * (s->K + 1) * s->target->cfg.vocab * 2;
+  SD_REQUIRE(logits_bytes >= need, "specdec_set_sampling: logits buffer %zu B < %zu B ([B][K+1][V] bf16)", logits_bytes, need);
+  SD_REQUIRE(temperature == temperature && temperature >= 0.f, "specdec_set_sampling: temperature %g", temperature);
+  SD_REQUIRE(top_k > 0 || !(top_p < 1.0f), "specdec_set_sampling: top_p=%g needs top_k (full-vocabulary nucleus is not supported)", top_p);
+  SD_REQUIRE(top_k <= 0 || (top_k < s->target->cfg.vocab ? top_k : s->target->cfg.vocab) <= 1024, "specdec_set_sampling: top_k=%d > 1024", top_k);
+  s->sample = 1;
+  s->temperature = temperature;
+  s->top_k = top_k;
+  s->top_p = top_p;
+  s->seed = seed;
+  s->logits = logits_buf;
+  s->draw = draw_counters;
+  s->stream_id = stream_ids;
   return 0;
 }
 

@@ -103,15 +103,31 @@ int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st) {
 // The row's state is advanced on the device for the common case so that the next step
 // can be launched without a host round trip; the host re-synchronises a row whenever
 // the reference's host-side rules (EOS cut, de-duplication, budget) say otherwise.
-__global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ int accept_scan(const SpecState& s, int b, int lane, int& my_t) {
   const int K = s.K, M = K + 1;
-  const int my_t = (lane < M) ? s.target_ids[b * M + lane] : -1;
+  my_t = (lane < M) ? s.target_ids[b * M + lane] : -1;
   const bool match = (lane < K) && (my_t == s.draft_tok[b * K + lane]);
   const unsigned long long m64 = __ballot(match);
   const unsigned long long valid = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
   const unsigned long long miss = (~m64) & valid;
-  const int a = miss ? __builtin_ctzll(miss) : K;
+  return miss ? __builtin_ctzll(miss) : K;
+}
+
+// sampling mode: the accept length alone, so that the sampler knows which logits row to draw from
+__global__ __launch_bounds__(kWave) void accept_len_kernel(SpecState s) {
+  int my_t;
+  const int a = accept_scan(s, blockIdx.x, threadIdx.x, my_t);
+  if (threadIdx.x == 0) s.accept_len[blockIdx.x] = a;
+}
+
+__global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, int use_sampled) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int K = s.K, M = K + 1;
+  int my_t;
+  const int a = accept_scan(s, b, lane, my_t);
+  // sampled bonus token (pipeline.py:3140-3160 / :3351-3361): the token after the accepted prefix
+  // is drawn from the target distribution at that position instead of its argmax
+  if (use_sampled && lane == a && s.active[b]) my_t = s.sampled[b];
 
   // tokens emitted by this step
   //   mode 0 (generate_batch, pipeline.py:3059-3292): base tokens t_0..t_{a-1} + bonus t_a
@@ -133,9 +149,17 @@ __global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode) {
   }
 }
 
-int launch_accept(const SpecState& s, int mode, hipStream_t st) {
+int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st) {
   SD_REQUIRE(s.K >= 1 && s.K <= 63, "accept: K=%d out of range 1..63", s.K);
-  hipLaunchKernelGGL(accept_kernel, dim3(s.B), dim3(kWave), 0, st, s, mode);
+  SD_REQUIRE(!use_sampled || (s.sampled && mode == 0), "accept: sampled bonus needs the bonus emit mode");
+  hipLaunchKernelGGL(accept_kernel, dim3(s.B), dim3(kWave), 0, st, s, mode, use_sampled);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_accept_len(const SpecState& s, hipStream_t st) {
+  SD_REQUIRE(s.K >= 1 && s.K <= 63, "accept: K=%d out of range 1..63", s.K);
+  hipLaunchKernelGGL(accept_len_kernel, dim3(s.B), dim3(kWave), 0, st, s);
   SD_LAUNCH_CHECK();
   return 0;
 }

@@ -40,6 +40,11 @@ SIGNATURES = {
         [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
          _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_void_p, _c_size, _c_void_p],
     ),
+    "sd_sample_token": (
+        _c_int,
+        [_c_void_p, _c_int, _c_i64, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, ctypes.c_float, _c_int, ctypes.c_float,
+         ctypes.c_uint64, _c_void_p, ctypes.c_uint32, _c_void_p, _c_void_p, _c_void_p],
+    ),
     "sd_kv_append": (
         _c_int,
         [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
@@ -74,6 +79,8 @@ SIGNATURES = {
     "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "sd_specdec_destroy": (_c_int, [_c_void_p]),
     "sd_specdec_set_row": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "sd_specdec_set_sampling": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_int, ctypes.c_float, ctypes.c_uint64,
+                                         _c_void_p, _c_size, _c_void_p, _c_void_p]),
     "sd_specdec_step": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int]),
     "sd_specdec_sync": (_c_int, [_c_void_p, _c_void_p]),
     "sd_specdec_record": (ctypes.POINTER(ctypes.c_int32), [_c_void_p]),

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -207,6 +207,36 @@ class HipSpecDec:
         with torch.cuda.device(self.device):
             _abi.check(self.lib.sd_specdec_set_row(self.handle, b, int(seq_len), int(prev_tok), int(last_tok),
                                                    1 if active else 0, self.stream_t.cuda_stream), "sd_specdec_set_row")
+
+    def set_sampling(self, enable: bool, temperature: float = 1.0, top_k: Optional[int] = None,
+                     top_p: Optional[float] = None, seed: int = 0, stream_ids: Optional[Sequence[int]] = None,
+                     draw_counts: Optional[Sequence[int]] = None):
+        """Sampled bonus token inside the step (sd_specdec_set_sampling). Draw counters start at
+        `draw_counts` (default 0: a new run)."""
+        with torch.cuda.device(self.device):
+            if not enable:
+                _abi.check(self.lib.sd_specdec_set_sampling(self.handle, 0, 1.0, 0, 1.0, 0, None, 0, None, None),
+                           "sd_specdec_set_sampling")
+                self.sampling = False
+                return
+            V = self.target.weights.config.vocab
+            if getattr(self, "_logits", None) is None:
+                self._logits = torch.empty((self.B, self.K + 1, V), dtype=torch.bfloat16, device=self.device)
+            self._draw = torch.tensor(list(draw_counts) if draw_counts is not None else [0] * self.B, dtype=torch.int32,
+                                      device=self.device)
+            sid = list(stream_ids) if stream_ids is not None else list(range(self.B))
+            self._stream_ids = torch.tensor(sid, dtype=torch.int32, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+            _abi.check(self.lib.sd_specdec_set_sampling(
+                self.handle, 1, float(temperature), int(top_k) if top_k else 0, 1.0 if top_p is None else float(top_p),
+                int(seed) & (2 ** 64 - 1), self._logits.data_ptr(), self._logits.numel() * 2, self._draw.data_ptr(),
+                self._stream_ids.data_ptr()), "sd_specdec_set_sampling")
+            self.sampling = True
+
+    @property
+    def step_logits(self) -> torch.Tensor:
+        """[B][K+1][V] bf16 logits of the last verify forward (sampling mode only)."""
+        return self._logits
 
     def step(self, use_graph: bool = True, two_streams: bool = True):
         with torch.cuda.device(self.device):

@@ -294,3 +294,40 @@ def kv_append_with_mask_hip(
         )
     _abi.check(rc, "sd_kv_append_masked")
     return out_k, out_v
+
+
+def sample_token_hip(logits: torch.Tensor, temperature: float, top_k: Optional[int] = None, top_p: Optional[float] = None,
+                     seed: int = 0, draw: int = 0, pos: Optional[torch.Tensor] = None, rows_per_entry: int = 1,
+                     draw_counters: Optional[torch.Tensor] = None, stream_ids: Optional[torch.Tensor] = None,
+                     active: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sampled token per entry (sd_sample_token): the device form of the reference's
+    `sample_bonus_token_from_logits(..., do_sample=True)` (src/specdec/core/pipeline.py:48-147).
+
+    logits: [rows, V] (or [V]) f32/bf16/f16 on the GPU, unit stride along V. Entry b reads row
+    b*rows_per_entry + pos[b]. Returns int32 [entries]. `draw` (or the int32 `draw_counters`, read
+    and incremented on the device) and `stream_ids` select the Philox value; see include/specdec_hip.h."""
+    lib = _abi.load()
+    if logits.dim() == 1:
+        logits = logits.unsqueeze(0)
+    if logits.dim() != 2:
+        raise ValueError(f"sample_token: logits must be [rows, V], got {tuple(logits.shape)}")
+    dev = _require_device("sample_token", logits)
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    rows, V = logits.shape
+    if rows % rows_per_entry:
+        raise ValueError(f"sample_token: {rows} rows is not a multiple of rows_per_entry={rows_per_entry}")
+    B = rows // rows_per_entry
+    for name, t in (("pos", pos), ("draw_counters", draw_counters), ("stream_ids", stream_ids), ("active", active)):
+        if t is not None and (t.device != dev or t.dtype != torch.int32 or t.numel() != B or not t.is_contiguous()):
+            raise ValueError(f"sample_token: {name} must be a contiguous int32 [{B}] tensor on {dev}")
+    k = int(top_k) if top_k else 0
+    p = 1.0 if top_p is None else float(top_p)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(dev):
+        _abi.check(lib.sd_sample_token(logits.data_ptr(), sd_dtype(logits.dtype), logits.stride(0), B, V, ptr(pos),
+                                       int(rows_per_entry), ptr(active), float(temperature), k, p, int(seed) & (2 ** 64 - 1),
+                                       ptr(draw_counters), int(draw) & 0xFFFFFFFF, ptr(stream_ids), out.data_ptr(),
+                                       _stream_ptr(dev)), "sd_sample_token")
+    return out

@@ -14,8 +14,11 @@ in `_rules_batch` / `_rules_single`). When those rules leave a row where the dev
 assumed (the common case) nothing else happens; when they do not (a de-duplication
 dropped or rewound tokens), the row's caches are rebuilt from its sequence.
 
-Greedy decoding (`do_sample=False`) is the device-resident path. Sampling is not on it
-yet and is refused loudly rather than served from a slower substitute.
+`generate_batch(do_sample=True)` samples what the reference samples there — only the token after
+the accepted prefix (`sample_bonus_token_from_logits`, :3156/:3231/:3355; drafting and verification
+stay greedy, :2400/:2645) — inside the same captured step (csrc/sample.hip). `generate(do_sample=True)`
+lets HF sample inside both models from the global torch generator (:1019-1081); that has no
+reproducible restatement and is refused loudly.
 """
 
 from __future__ import annotations
@@ -63,11 +66,11 @@ def _clamp(tok: int, vocab: int) -> int:
 
 
 class _Row:
-    __slots__ = ("seq", "generated", "active", "proposed", "accepted")
+    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws")
 
     def __init__(self, seq: List[int]):
         self.seq, self.generated, self.active = seq, [], True
-        self.proposed = self.accepted = 0
+        self.proposed = self.accepted = self.draws = 0
 
 
 class SpeculativePipeline:
@@ -183,9 +186,12 @@ class SpeculativePipeline:
         loop.set_row(b, len(seq), seq[-2] if len(seq) >= 2 else 0, seq[-1], row.active)
 
     # ------------------------------------------------------------------ host-side rules
-    def _rules_batch(self, row: _Row, k: int, a: int, t: List[int], max_tokens: int, eos: Optional[int]) -> None:
+    def _rules_batch(self, row: _Row, k: int, a: int, t: List[int], max_tokens: int, eos: Optional[int],
+                     resample=None) -> None:
         """One row of one generate_batch step (pipeline.py:3018-3590), from the step record:
-        a = accepted length, t[i] = target argmax after the row's sequence + d_1..d_i."""
+        a = accepted length, t[i] = target argmax after the row's sequence + d_1..d_i (sampling mode:
+        t[a] is the token the device sampled at position a; `resample(pos)` draws at another position
+        with the same Philox draw — only an EOS-cut full acceptance needs it)."""
         V = self.base_lm.vocab_size
         gen = row.generated
         if a > 0:
@@ -193,7 +199,8 @@ class SpeculativePipeline:
             if eos is not None and eos in acc:           # accepted EOS: cut there, row stops (:3120-3131)
                 acc = acc[: acc.index(eos)]
                 row.active = False
-            bonus = _clamp(t[a] if a < k else t[len(acc)], V)   # (:3140-3231)
+            pos = a if a < k else len(acc)                # (:3140-3231) the extra forward runs over seq + cut acc
+            bonus = _clamp(t[pos] if (resample is None or pos == a) else resample(pos), V)
             if eos is not None and bonus == eos:         # bonus EOS stays in the output (:3274-3280)
                 row.active = False
             acc.append(bonus)
@@ -245,14 +252,16 @@ class SpeculativePipeline:
             row.active = False
 
     # ------------------------------------------------------------------ the loop
-    def start_session(self, prompts: List[List[int]], max_tokens: int, emit_mode: int) -> "DecodeSession":
+    def start_session(self, prompts: List[List[int]], max_tokens: int, emit_mode: int,
+                      sampling: Optional[Dict[str, Any]] = None) -> "DecodeSession":
         """Prefill + device state for a batch of rows; `advance()` then runs one step at a time
         (generate / generate_batch drive it to completion, bench.py times exact step counts)."""
-        return DecodeSession(self, prompts, max_tokens, emit_mode)
+        return DecodeSession(self, prompts, max_tokens, emit_mode, sampling)
 
-    def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int):
+    def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int,
+                sampling: Optional[Dict[str, Any]] = None):
         t_start = time.time()
-        sess = self.start_session(prompts, max_tokens, emit_mode)
+        sess = self.start_session(prompts, max_tokens, emit_mode, sampling)
         while sess.step < step_limit and sess.any_active():
             if not sess.advance():
                 break
@@ -263,11 +272,19 @@ class SpeculativePipeline:
         return sess.rows, st
 
     # ------------------------------------------------------------------ public API
-    def _check_sampling(self, do_sample: bool) -> None:
-        if do_sample:
-            raise NotImplementedError(
-                "do_sample=True: sampled decoding is not on the HIP path yet (DESIGN.md, 'next'); "
-                "call with do_sample=False (greedy, the SPECDEC_DETERMINISTIC configuration)")
+    def _sampling_config(self, do_sample: bool, temperature: float, kwargs: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+        """Sampler parameters of a do_sample=True run (kwargs over config, pipeline.py:3148-3153)."""
+        if not do_sample:
+            return None
+        top_p = kwargs.get("top_p", self.config.get("top_p", None))
+        top_k = kwargs.get("top_k", self.config.get("top_k", None))
+        if (not top_k or top_k <= 0) and top_p is not None and top_p < 1.0:
+            raise NotImplementedError("do_sample=True with top_p < 1 and no top_k: full-vocabulary nucleus sampling is "
+                                      "not on the HIP path (pass top_k <= 1024, or top_p=1.0)")
+        if top_k and min(int(top_k), self.base_lm.vocab_size) > 1024:
+            raise NotImplementedError(f"do_sample=True: top_k={top_k} > 1024 is not on the HIP path")
+        return {"temperature": float(temperature), "top_k": int(top_k) if top_k else None,
+                "top_p": None if top_p is None else float(top_p), "seed": int(kwargs.get("seed", self.config.get("seed") or 0))}
 
     def generate(self, prompt: PromptLike, max_tokens: Optional[int] = None, temperature: Optional[float] = None,
                  do_sample: Optional[bool] = None, **kwargs) -> Dict[str, Any]:
@@ -277,7 +294,11 @@ class SpeculativePipeline:
         max_tokens = max_tokens or self.config["max_new_tokens"]
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
-        self._check_sampling(do_sample)
+        if do_sample:
+            raise NotImplementedError(
+                "generate(do_sample=True): the reference lets HF sample inside the draft and the base model from the "
+                "global torch generator (pipeline.py:1019-1081); that is not restated. Use generate_batch(do_sample=True) "
+                "(sampled bonus token, reproducible) or do_sample=False")
         ids = self._encode(prompt)
         rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens)
         r = rows[0]
@@ -307,9 +328,9 @@ class SpeculativePipeline:
         max_tokens = max_tokens or self.config["max_new_tokens"]
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
-        self._check_sampling(do_sample)
+        sampling = self._sampling_config(do_sample, temperature, kwargs)
         ids = [self._encode(p) for p in prompts]
-        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens)
+        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling)
         total_ms = st["total_ms"]
         tot_prop = sum(r.proposed for r in rows)
         tot_acc = sum(r.accepted for r in rows)
@@ -354,8 +375,12 @@ class SpeculativePipeline:
 class DecodeSession:
     """One batch of rows being decoded: host mirror of the sequences + the device loop."""
 
-    def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int):
+    def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int,
+                 sampling: Optional[Dict[str, Any]] = None):
         self.pipe, self.max_tokens, self.emit_mode = pipe, max_tokens, emit_mode
+        self.sampling = sampling
+        if sampling is not None and emit_mode != HipSpecDec.EMIT_BONUS:
+            raise ValueError("sampling is a generate_batch (bonus-token) feature")
         self.rows = [_Row(list(p)) for p in prompts]
         for r in self.rows:
             if not r.seq:
@@ -370,11 +395,37 @@ class DecodeSession:
         self.loop.join_current_stream()
         for b, r in enumerate(self.rows):
             pipe._set_row(self.loop, b, r)
+        self._apply_sampling()
         self.stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0}
         self.step = 0
 
     def any_active(self) -> bool:
         return any(r.active for r in self.rows)
+
+    def _apply_sampling(self) -> None:
+        """Loops are cached per (batch, K): (re)configure the one in use for this run."""
+        sp = self.sampling
+        if sp is None:
+            if getattr(self.loop, "sampling", False):
+                self.loop.sync()
+                self.loop.set_sampling(False)
+            return
+        self.loop.sync()
+        self.loop.set_sampling(True, sp["temperature"], sp["top_k"], sp["top_p"], sp["seed"],
+                               stream_ids=list(range(len(self.rows))), draw_counts=[r.draws for r in self.rows])
+
+    def _resampler(self, b: int, row: _Row):
+        """Draw at another position of the step's logits with the row's current Philox draw."""
+        from specdec_hip.ops import sample_token_hip
+
+        sp, loop = self.sampling, self.loop
+
+        def resample(pos: int) -> int:
+            with torch.cuda.stream(loop.stream_t):
+                tok = sample_token_hip(loop.step_logits[b, pos], sp["temperature"], sp["top_k"], sp["top_p"], seed=sp["seed"],
+                                       draw=row.draws, stream_ids=torch.tensor([b], dtype=torch.int32, device="cuda"))
+                return int(tok.item())
+        return resample
 
     def advance(self) -> bool:
         """One draft-then-verify step for every active row. Returns False when the controller
@@ -395,10 +446,12 @@ class DecodeSession:
                 self.loop.join_current_stream()
                 for b, r in enumerate(rows):
                     pipe._set_row(self.loop, b, r)
+                self._apply_sampling()
         k, loop, rt = self.k, self.loop, self.rt
         t0 = time.time()
         loop.step(use_graph=True)
         rec = loop.sync()
+        self.last_record = rec
         stats["device_ms"] += (time.time() - t0) * 1e3
         for b, r in enumerate(rows):
             if not r.active:
@@ -407,9 +460,14 @@ class DecodeSession:
             t = [int(x) for x in rec.target_ids[b]]
             d = [int(x) for x in rec.draft_tokens[b]]
             before, acc0 = r.seq, r.accepted
+            if self.sampling is not None:
+                t[a] = int(rec.new_tokens[b][a])       # the token the device sampled at position a
             assumed = before + t[: int(rec.n_new[b])]  # what the device advanced to
             if self.emit_mode == HipSpecDec.EMIT_BONUS:
-                pipe._rules_batch(r, k, a, t, self.max_tokens, self.eos)
+                pipe._rules_batch(r, k, a, t, self.max_tokens, self.eos,
+                                  self._resampler(b, r) if self.sampling is not None else None)
+                if self.sampling is not None:
+                    r.draws += 1
             else:
                 pipe._rules_single(r, k, a, d, t, self.max_tokens, self.eos)
             stats["proposed"] += k

@@ -52,18 +52,23 @@ class RowState:
     proposed: int = 0
     accepted: int = 0
     steps: int = 0
+    draws: int = 0                      # sampled steps so far (index of the next Philox draw)
 
 
 def step_rules_batch(row: RowState, k: int, a: int, draft: Sequence[int], t: Sequence[int],
-                     max_tokens: int, eos: Optional[int], vocab: int) -> List[int]:
+                     max_tokens: int, eos: Optional[int], vocab: int, bonus_at=None) -> List[int]:
     """One row of one generate_batch step. `t[i]` is the target's greedy token after the
     row's sequence + draft[:i] (i = 0..k), which for i <= a is what the reference's
     autoregressive base pass yields (base_tokens[i], and the extra forward for i == k).
 
     Returns the tokens appended to the row's SEQUENCE (which the de-duplication can make
     differ from what was appended to its generated list).
+
+    `bonus_at(pos)` (do_sample=True): the token SAMPLED from the target logits of position pos
+    (sample_bonus_token_from_logits, :3156 / :3231 / :3355); greedy uses t[pos].
     """
     clamp = lambda x: max(0, min(int(x), vocab - 1))  # validate_and_clamp_tokens
+    pick = bonus_at if bonus_at is not None else (lambda pos: t[pos])
     gen = row.generated
     if a > 0:
         acc = [clamp(x) for x in t[:a]]                       # :3059-3075 accepted = base_tokens[:a]
@@ -72,7 +77,7 @@ def step_rules_batch(row: RowState, k: int, a: int, draft: Sequence[int], t: Seq
             row.active = False
         # bonus: logits at position a (a < k, :3140-3163) or the extra forward over
         # seq + acc (a == k, :3164-3231; acc possibly EOS-cut, so position len(acc))
-        bonus = clamp(t[a] if a < k else t[len(acc)])
+        bonus = clamp(pick(a if a < k else len(acc)))
         if eos is not None and bonus == eos:                  # :3274-3280 bonus EOS is kept
             row.active = False
         acc = acc + [bonus]
@@ -86,7 +91,7 @@ def step_rules_batch(row: RowState, k: int, a: int, draft: Sequence[int], t: Seq
         accepted_len = len(tokens_to_add)
         accepted_tokens = list(tokens_to_add)
     else:
-        first = clamp(t[0])                                   # :3328-3345 first base token
+        first = clamp(pick(0))                                # :3328-3345 first base token
         accepted_tokens = [first]
         if eos is not None and first == eos:                  # :3360-3365 EOS dropped, row stops
             row.active = False
@@ -180,13 +185,19 @@ class OraclePipeline:
             return draft, t, a
         # one cached pass over seq + draft: logits at the last K+1 positions
         lg, _ = self.base.forward(torch.tensor([seq + draft], dtype=torch.int64))
-        t = lg[0, len(seq) - 1 :].argmax(-1).tolist()
+        self.last_logits = lg[0, len(seq) - 1 :]     # [K+1][V]: what the sampled bonus token is drawn from
+        t = self.last_logits.argmax(-1).tolist()
         a = longest_prefix(draft, t)
         return draft, t, a
 
     def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int,
-                       max_steps: Optional[int] = None) -> List[Dict]:
-        """`max_steps` (not in the reference) bounds a timing sample to a number of steps."""
+                       max_steps: Optional[int] = None, sampling: Optional[Dict] = None) -> List[Dict]:
+        """`max_steps` (not in the reference) bounds a timing sample to a number of steps.
+        `sampling` = {temperature, top_k, top_p, seed} turns on do_sample=True: drafting and
+        verification stay greedy (pipeline.py:2400, :2645); only the token after the accepted
+        prefix is sampled (oracle/sampling_ref.py), one Philox draw per row per step, stream = row."""
+        if sampling is not None and self.reprefill:
+            raise ValueError("sampling needs the cached verify pass (reprefill=False)")
         rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
         self.trace = []
         t0 = time.time()
@@ -200,7 +211,18 @@ class OraclePipeline:
                     continue
                 draft, t, a = self._propose_and_verify(r.seq)
                 before = len(r.seq)
-                appended = step_rules_batch(r, self.k, a, draft, t, max_tokens, self.eos, self.vocab)
+                bonus_at = None
+                if sampling is not None:
+                    from .sampling_ref import sample_token_ref
+
+                    lg_rows = self.last_logits.float().numpy()
+
+                    def bonus_at(pos, _lg=lg_rows, _r=r, _i=i):
+                        return sample_token_ref(_lg[pos], sampling["temperature"], sampling.get("top_k"), sampling.get("top_p"),
+                                                int(sampling.get("seed", 0)), _r.draws, _i)
+                appended = step_rules_batch(r, self.k, a, draft, t, max_tokens, self.eos, self.vocab, bonus_at)
+                if sampling is not None:
+                    r.draws += 1
                 self.trace.append({"step": step, "row": i, "a": a, "draft": draft, "t": t[: a + 1],
                                    "appended": appended, "seq_len": before})
         dt = time.time() - t0

@@ -262,6 +262,28 @@ def gen_hostlogic():
         V = int(rng.integers(10, 100))
         ids = torch.from_numpy(rng.integers(-5, V + 5, size=(2, 7), dtype=np.int64))
         out["clamp"].append({"V": V, "ids": ids.tolist(), "out": validate_and_clamp_tokens(ids, V, "g").tolist()})
+    # sampled bonus token (do_sample=True): empirical histogram of the reference function's own draws,
+    # which pins the kept set exactly (tokens never drawn outside it) and the probabilities statistically
+    out["sampling"] = []
+    srng = np.random.default_rng(77)
+    for case in range(14):
+        V = int(srng.integers(40, 600))
+        seed = 9700 + case
+        scale = float(srng.choice([1.0, 3.0, 6.0]))
+        logits = torch.from_numpy(np.random.default_rng(seed).standard_normal(V).astype(np.float32)) * scale
+        if case % 5 == 4:   # bf16-like ties around the cut
+            logits = logits.to(torch.bfloat16).float()
+        top_k = int(srng.choice([1, 3, 8, 20, 50, 50, 64]))
+        top_p = float(srng.choice([1.0, 0.95, 0.9, 0.9, 0.6, 0.3]))
+        temp = float(srng.choice([1.0, 0.7, 0.7, 1.5, 0.2]))
+        n_draws = 4000
+        torch.manual_seed(4242 + case)
+        counts = {}
+        for _ in range(n_draws):
+            t = int(sample_bonus_token_from_logits(logits, temp, True, top_p=top_p, top_k=top_k, vocab_size=V)[0])
+            counts[t] = counts.get(t, 0) + 1
+        out["sampling"].append({"seed": seed, "V": V, "scale": scale, "bf16": case % 5 == 4, "top_k": top_k, "top_p": top_p,
+                                "temperature": temp, "n_draws": n_draws, "counts": {str(k): v for k, v in sorted(counts.items())}})
     with open(os.path.join(HERE, "hostlogic_golden.json"), "w") as f:
         json.dump(out, f)
     print("hostlogic goldens:", {k: len(v) for k, v in out.items()})

@@ -119,7 +119,7 @@ def test_loud_refusals():
     drf, tgt = tiny_pair()
     pipe = _pipe(drf, tgt, 2)
     with pytest.raises(NotImplementedError, match="do_sample"):
-        pipe.generate_batch([[5, 6, 7]], max_tokens=4, do_sample=True)
+        pipe.generate([5, 6, 7], max_tokens=4, do_sample=True)
     from src.specdec import SpeculativePipeline
 
     with pytest.raises(ValueError, match="implementation"):
@@ -128,3 +128,23 @@ def test_loud_refusals():
     import src.specdec
 
     assert specdec is src.specdec and specdec.SpecDecRunner is specdec.SpeculativePipeline
+
+
+def test_config1_gpt2_distilgpt2_shapes_k2():
+    """BASELINE config 1: GPT-2 (12 L) target + DistilGPT2 (6 L) draft, K=2, batch 1 — full shapes
+    (V = 50257 is odd, LayerNorm + biases + learned positions + gelu_new), synthetic weights. `generate`
+    and `generate_batch` on the GPU equal the oracle's reference-faithful loop token for token."""
+    from specdec_hip import weights as W
+
+    tgt = W.synthetic_gpt2(W.GPT2_SMALL, seed=0, device="cpu")
+    drf = W.synthetic_gpt2(W.DISTILGPT2, seed=1, device="cpu", embed_from=tgt, flip_fraction=0.3)
+    prompt = synthetic_prompts(1, 12, tgt.config.vocab)[0].tolist()
+    pipe = _pipe(drf, tgt, 2)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=2, eos_token_id=tgt.config.eos_token_id)
+    got, want = pipe.generate(prompt, max_tokens=12, do_sample=False), oracle.generate(prompt, 12)
+    assert got["generated_tokens"] == want["generated_tokens"]
+    assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
+    assert 0 < got["accepted"] < got["proposed"] + got["steps"]
+    gb, wb = pipe.generate_batch([prompt], max_tokens=12, do_sample=False)[0], oracle.generate_batch([prompt], 12)[0]
+    assert gb["generated_tokens"] == wb["generated_tokens"]
+    assert (gb["proposed"], gb["accepted"]) == (wb["proposed"], wb["accepted"])
