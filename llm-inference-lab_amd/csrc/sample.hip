@@ -4,15 +4,18 @@
 // which the reference runs on the host per row per step with a full sort over the vocabulary
 // (:107) and torch.multinomial on the global generator. Here one 1024-thread workgroup per row:
 //
-//   1. radix select of the k-th largest logit on a 52-bit composite key
+//   1. a lower bound of the k-th largest logit on a 52-bit composite key
 //        [32-bit order-preserving value key][20-bit inverted index]
 //      (so "value descending, then index ascending" is a total order and ties at the cut are
-//      decided the same way everywhere). Each pass scans the row (L2/MALL resident: the lm_head
-//      epilogue has just written it), histograms the next 10-11 key bits of the elements that
-//      match the prefix decided so far in LDS, and one wave picks the digit holding the k-th
-//      element. The passes stop as soon as that digit's bucket fits the candidate buffer
-//      (bf16 logits: one or two passes);
-//   2. one gather scan of everything at or above the bucket, bitonic sort in LDS (<= 4096 keys);
+//      decided the same way everywhere). Fast path: every thread keeps the maximum of the elements
+//      it scans (16-byte loads; the row is L2/MALL resident, the lm_head epilogue has just written
+//      it); the k-th largest of the 1024 thread maxima (bitonic sort in LDS) cannot exceed the k-th
+//      largest element, so everything below it is out. For real logits that leaves ~k..2k
+//      candidates. If more than 4096 survive (maxima concentrated in few threads), fall back to a
+//      radix select: each pass histograms the next 10-11 key bits of the elements that match the
+//      prefix decided so far in LDS, one wave picks the digit holding the k-th element, and the
+//      passes stop as soon as that digit's bucket fits the candidate buffer;
+//   2. one gather scan of everything at or above the bound, bitonic sort in LDS (<= 4096 keys);
 //   3. the k survivors: x/T, exp(x/T - max), nucleus cut on the inclusive cumulative probability
 //      (first token always kept), inversion of ONE Philox4x32-10 uniform through the cumulative
 //      sums — in float64, sequentially in sorted order, exactly as oracle/sampling_ref.py.
@@ -85,6 +88,33 @@ __device__ __forceinline__ uint64_t composite_key(float x, int i) {
   return (static_cast<uint64_t>(order_key(x)) << kIdxBits) | static_cast<uint64_t>(((1u << kIdxBits) - 1u) - static_cast<uint32_t>(i));
 }
 
+// f(value, index) for every element of the row, 16-byte loads when the row allows it.
+// The visiting order differs between the two forms; every use below is order-independent.
+template <typename F>
+__device__ __forceinline__ void for_each_logit(const void* row, int dtype, int V, int tid, F&& f) {
+  const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+  if (dtype == SD_F32 && aligned && (V & 3) == 0) {
+    const float4* p = static_cast<const float4*>(row);
+    for (int v = tid; v < (V >> 2); v += kSampleThreads) {
+      const float4 q = p[v];
+      f(q.x, 4 * v); f(q.y, 4 * v + 1); f(q.z, 4 * v + 2); f(q.w, 4 * v + 3);
+    }
+  } else if (dtype == SD_BF16 && aligned && (V & 7) == 0) {
+    const uint4* p = static_cast<const uint4*>(row);
+    for (int v = tid; v < (V >> 3); v += kSampleThreads) {
+      const uint4 q = p[v];
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f(__uint_as_float(w[j] << 16), 8 * v + 2 * j);
+        f(__uint_as_float(w[j] & 0xffff0000u), 8 * v + 2 * j + 1);
+      }
+    }
+  } else {
+    for (int i = tid; i < V; i += kSampleThreads) f(load_logit(row, dtype, i), i);
+  }
+}
+
 __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const SampleArgs a) {
   __shared__ uint32_t hist[2048];
   __shared__ uint64_t sel[kSampleSort];
@@ -97,90 +127,112 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const Sampl
   const int V = a.V;
   const int k = min(a.top_k, V);
 
-  // ---- 1. radix select on the composite key, most significant digits first
-  const int widths[5] = {11, 11, 10, 10, 10};
-  uint64_t prefix = 0;       // decided high bits (right-aligned)
-  int decided = 0;           // number of decided bits (of 52)
-  int need = k;              // rank of the wanted element inside the current bucket (1-based from the top)
-  for (int p = 0; p < 5; ++p) {
-    const int w = widths[p];
-    const int shift = 52 - decided - w;
-    for (int i = tid; i < 2048; i += kSampleThreads) hist[i] = 0;
+  // gather every element whose composite key, shifted right by `shift`, is >= `bound`
+  auto gather = [&](uint64_t bound, int shift) {
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < kSampleSort; i += kSampleThreads) sel[i] = 0;
     __syncthreads();
-    for (int i = tid; i < V; i += kSampleThreads) {
-      const uint64_t c = composite_key(load_logit(row, a.dtype, i), i);
-      if ((c >> (shift + w)) == prefix) atomicAdd(&hist[(c >> shift) & ((1u << w) - 1u)], 1u);
-    }
+    for_each_logit(row, a.dtype, V, tid, [&](float x, int i) {
+      const uint64_t c = composite_key(x, i);
+      if ((c >> shift) >= bound) {
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+        if (slot < static_cast<uint32_t>(kSampleSort)) sel[slot] = c + 1;  // 0 stays "empty" and sorts last
+      }
+    });
     __syncthreads();
-    if (wave == 0) {
-      // lane l owns digits [32 l, 32 l + 32); scan from the top digit down
-      const int nb = 1 << w;
-      uint32_t local = 0;
-      for (int j = 0; j < 32; ++j) {
-        const int d = lane * 32 + j;
-        if (d < nb) local += hist[d];
-      }
-      // above = sum of `local` over higher lanes
-      uint32_t incl = local;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(incl, off, 64);
-        if (lane + off < 64) incl += o;
-      }
-      uint32_t above = incl - local;
-      if (above < static_cast<uint32_t>(need) && incl >= static_cast<uint32_t>(need)) {
-        for (int j = 31; j >= 0; --j) {
-          const int d = lane * 32 + j;
-          if (d >= nb) continue;
-          const uint32_t h = hist[d];
-          if (above + h >= static_cast<uint32_t>(need)) {
-            s_digit = d;
-            s_above = above;
-            s_bucket = h;
-            break;
-          }
-          above += h;
+  };
+  // descending bitonic sort of sel[0, n), n a power of two
+  auto sort_desc = [&](int n) {
+    for (int size = 2; size <= n; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < n / 2; t += kSampleThreads) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const uint64_t x = sel[lo], y = sel[hi];
+          if ((x < y) == desc) { sel[lo] = y; sel[hi] = x; }
         }
+        __syncthreads();
       }
     }
+  };
+
+  // ---- 1a. fast path: the k-th largest thread maximum bounds the k-th largest element from below
+  {
+    uint64_t best = 0;
+    for_each_logit(row, a.dtype, V, tid, [&](float x, int i) {
+      const uint64_t c = composite_key(x, i);
+      best = c > best ? c : best;
+    });
+    sel[tid] = best;  // threads without an element hold 0: below every real key
     __syncthreads();
-    prefix = (prefix << w) | s_digit;
-    decided += w;
-    need -= static_cast<int>(s_above);
-    const uint32_t bucket = s_bucket;
+    sort_desc(kSampleThreads);
+    const uint64_t tau = sel[k - 1];  // k <= min(1024, V): at least k threads saw an element
     __syncthreads();
-    if (bucket <= static_cast<uint32_t>(kSampleCap)) break;
+    gather(tau, 0);
   }
 
-  // ---- 2. gather everything >= the bucket's lower bound, sort descending
-  if (tid == 0) s_cnt = 0;
-  for (int i = tid; i < kSampleSort; i += kSampleThreads) sel[i] = 0;
-  __syncthreads();
-  {
-    const int shift = 52 - decided;
-    for (int i = tid; i < V; i += kSampleThreads) {
-      const uint64_t c = composite_key(load_logit(row, a.dtype, i), i);
-      if ((c >> shift) >= prefix) {
-        const uint32_t slot = atomicAdd(&s_cnt, 1u);
-        if (slot < static_cast<uint32_t>(kSampleSort)) sel[slot] = c + 1;  // +1: 0 stays "empty" (index field never saturates: i >= 0)
-      }
-    }
-  }
-  __syncthreads();
-  int n_sort = 2;  // next power of two >= gathered count (workgroup-uniform)
-  while (n_sort < static_cast<int>(s_cnt)) n_sort <<= 1;
-  for (int size = 2; size <= n_sort; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < n_sort / 2; t += kSampleThreads) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const uint64_t x = sel[lo], y = sel[hi];
-        if ((x < y) == desc) { sel[lo] = y; sel[hi] = x; }
+  // ---- 1b. fallback: radix select on the composite key, most significant digits first
+  if (s_cnt > static_cast<uint32_t>(kSampleSort)) {
+    const int widths[5] = {11, 11, 10, 10, 10};
+    uint64_t prefix = 0;       // decided high bits (right-aligned)
+    int decided = 0;           // number of decided bits (of 52)
+    int need = k;              // rank of the wanted element inside the current bucket (1-based from the top)
+    for (int p = 0; p < 5; ++p) {
+      const int w = widths[p];
+      const int shift = 52 - decided - w;
+      for (int i = tid; i < 2048; i += kSampleThreads) hist[i] = 0;
+      __syncthreads();
+      for_each_logit(row, a.dtype, V, tid, [&](float x, int i) {
+        const uint64_t c = composite_key(x, i);
+        if ((c >> (shift + w)) == prefix) atomicAdd(&hist[(c >> shift) & ((1u << w) - 1u)], 1u);
+      });
+      __syncthreads();
+      if (wave == 0) {
+        // lane l owns digits [32 l, 32 l + 32); scan from the top digit down
+        const int nb = 1 << w;
+        uint32_t local = 0;
+        for (int j = 0; j < 32; ++j) {
+          const int d = lane * 32 + j;
+          if (d < nb) local += hist[d];
+        }
+        uint32_t incl = local;  // suffix sum over lanes >= this one
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_down(incl, off, 64);
+          if (lane + off < 64) incl += o;
+        }
+        uint32_t above = incl - local;
+        if (above < static_cast<uint32_t>(need) && incl >= static_cast<uint32_t>(need)) {
+          for (int j = 31; j >= 0; --j) {
+            const int d = lane * 32 + j;
+            if (d >= nb) continue;
+            const uint32_t h = hist[d];
+            if (above + h >= static_cast<uint32_t>(need)) {
+              s_digit = d;
+              s_above = above;
+              s_bucket = h;
+              break;
+            }
+            above += h;
+          }
+        }
       }
       __syncthreads();
+      prefix = (prefix << w) | s_digit;
+      decided += w;
+      need -= static_cast<int>(s_above);
+      const uint32_t bucket = s_bucket;
+      __syncthreads();
+      if (bucket <= static_cast<uint32_t>(kSampleCap)) break;
     }
+    gather(prefix, 52 - decided);
   }
+
+  // ---- 2. sort the candidates (>= k of them, the k largest among them) descending
+  int n_sort = 2;  // next power of two >= gathered count (workgroup-uniform)
+  while (n_sort < static_cast<int>(s_cnt)) n_sort <<= 1;
+  sort_desc(n_sort);
 
   // ---- 3. the k survivors in sorted order: weights in float64
   const double T = static_cast<double>(a.temperature);

@@ -51,10 +51,18 @@ def test_ties_special_values_and_flat_rows():
     nan[77] = float("nan")
     negz = torch.zeros(300)
     negz[::2] = -0.0
-    for name, x in (("coarse", coarse), ("flat", flat), ("ninf", ninf), ("mixed", mixed), ("nan", nan), ("negz", negz)):
+    # large values concentrated in the elements 40 threads scan (16-byte vectors v with v % 1024 < 40):
+    # the thread-maxima bound lets > 4096 candidates through, which takes the radix-select path
+    conc = torch.randn(V, generator=g) * 0.1
+    vec = torch.arange(V) // 8
+    hot = (vec % 1024) < 40
+    conc[hot] = 5.0 + torch.rand(int(hot.sum()), generator=g) * 3
+    conc_ties = conc.to(torch.bfloat16).float()
+    for name, x in (("coarse", coarse), ("flat", flat), ("ninf", ninf), ("mixed", mixed), ("nan", nan), ("negz", negz),
+                    ("conc", conc), ("conc_ties", conc_ties), ("conc_bf16", conc.to(torch.bfloat16))):
         for top_k, top_p, T in ((50, 0.9, 0.7), (1024, None, 1.0), (7, 0.5, 3.0)):
             for draw in range(3):
-                want = S.sample_token_ref(x.numpy(), T, top_k, top_p, 5, draw, 0)
+                want = S.sample_token_ref(x.float().numpy(), T, top_k, top_p, 5, draw, 0)
                 assert _hip(x, T, top_k, top_p, 5, draw, 0) == want, (name, top_k, top_p, T, draw)
 
 
