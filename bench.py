@@ -211,7 +211,7 @@ def main():
     if not args.no_probe:
         tm = sess.rt["target"]
         st = torch.cuda.Stream()
-        usec, nbytes = tm.probe_gemv(tm.PROBE_GATE_UP, T=min(B * (K + 1), 9), iters=280, stream=st)
+        usec, nbytes = tm.probe_gemv(tm.PROBE_GATE_UP, T=min(B * (K + 1), tm.pass_tokens), iters=280, stream=st)
         ach = nbytes / (usec * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_mfma_kernel<EPI_SWIGLU> (target norm+gate/up+SwiGLU)",
                            "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK_BPS,
@@ -220,16 +220,16 @@ def main():
         # runs, FETCH_SIZE x2 on gfx950): counters cannot be read from inside this process, so the
         # figure comes from the committed summary of the same command (profiles/summarize.py)
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-        if os.path.exists(pmc) and min(B * (K + 1), 9) == 5:
+        if os.path.exists(pmc) and B * (K + 1) == 5:
             with open(pmc) as f:
                 t = json.load(f).get("gemv_mfma_kernel<2, false, 5>")
             if t:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc passes of bench.py)"
         others = {}
-        for name, which, T in (("target_lm_head", tm.PROBE_LM_HEAD, min(B * (K + 1), 9)),
-                               ("target_down", tm.PROBE_DOWN, min(B * (K + 1), 9)),
-                               ("target_o_proj", tm.PROBE_O, min(B * (K + 1), 9))):
+        for name, which, T in (("target_lm_head", tm.PROBE_LM_HEAD, min(B * (K + 1), tm.pass_tokens)),
+                               ("target_down", tm.PROBE_DOWN, min(B * (K + 1), tm.pass_tokens)),
+                               ("target_o_proj", tm.PROBE_O, min(B * (K + 1), tm.pass_tokens))):
             u, nb = tm.probe_gemv(which, T=T, iters=140, stream=st)
             others[name] = {"avg_launch_us": u, "GBps": nb / (u * 1e-6) / 1e9}
         dmod = sess.rt["draft"]

@@ -214,6 +214,10 @@ typedef struct sd_model sd_model;
 int sd_model_create(const sd_model_config* cfg, sd_model** out);
 int sd_model_destroy(sd_model* m);
 
+/* Tokens one pass of sd_model_forward covers: 64 when every matrix of the model has a shape the
+ * multi-token kernel (gemm_skinny.hip) handles, else 9. Larger B*M are tiled into passes. */
+int sd_model_pass_tokens(const sd_model* m);
+
 /* Scratch the forward needs (activations of one pass + argmax partials). */
 size_t sd_model_workspace_bytes(const sd_model* m);
 /* Bytes of ONE of the two cache tensors, bf16:

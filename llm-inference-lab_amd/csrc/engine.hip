@@ -31,11 +31,12 @@ struct sd_model {
   uint16_t* v_cache = nullptr;
   int B = 0, Lmax = 0;
   // workspace carve
-  uint16_t* x = nullptr;     // [9][d]
-  uint16_t* q = nullptr;     // [9][Hq*D]
-  uint16_t* attn = nullptr;  // [9][Hq*D]
-  uint16_t* act = nullptr;   // [9][ff]
-  float* part_val = nullptr; // [9][512]
+  uint16_t* x = nullptr;     // [64][d]
+  uint16_t* q = nullptr;     // [64][Hq*D]
+  uint16_t* attn = nullptr;  // [64][Hq*D]
+  uint16_t* act = nullptr;   // [64][ff]
+  float* part_val = nullptr; // [64][512]
+  int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
   int* part_idx = nullptr;
   int head_grid = 0;         // grid of the last lm_head launch (partials per token)
   std::vector<const void*> packed;  // per matrix (4 per layer + lm_head) or empty: row-major weights
@@ -50,7 +51,7 @@ constexpr int kMaxPartials = 512;
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static size_t workspace_bytes(const sd_model_config& c) {
-  const size_t T = kGemvMaxT;
+  const size_t T = kSkinnyMaxT;
   size_t n = 0;
   n += align_up(T * c.d_model * 2, 256);
   n += align_up(T * c.n_heads * c.head_dim * 2, 256) * 2;
@@ -59,7 +60,7 @@ static size_t workspace_bytes(const sd_model_config& c) {
   return n + 256;
 }
 
-// one pass: Bc rows x Mc tokens, Bc*Mc <= 9
+// one pass: Bc rows x Mc tokens, Bc*Mc <= m->max_t
 static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
                         int pos_off, int row0, int b0, int Bc, int Mc, int32_t* ids_out, int ids_stride,
                         void* logits_out, int logits_dtype, int logits_stride, int skip_head,
@@ -238,8 +239,9 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
   const int esz = (logits_dtype == SD_F32) ? 4 : 2;
   SD_REQUIRE(!logits_out || logits_dtype == SD_F32 || logits_dtype == SD_BF16, "forward: logits dtype %d", logits_dtype);
   const int V = m->cfg.vocab;
-  if (M <= kGemvMaxT) {
-    const int Bc = kGemvMaxT / M;
+  const int cap = (B * M <= kGemvMaxT) ? kGemvMaxT : m->max_t;  // tokens per pass
+  if (M <= cap) {
+    const int Bc = cap / M;
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? B - b0 : Bc;
       void* lo = logits_out ? static_cast<char*>(logits_out) + static_cast<size_t>(b0) * M * V * esz : nullptr;
@@ -249,10 +251,10 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
     }
     return 0;
   }
-  // long M (prefill): chunks of 9 positions, one row at a time, in position order
+  // long M (prefill): chunks of `cap` positions, one row at a time, in position order
   for (int b0 = 0; b0 < B; ++b0) {
-    for (int m0 = 0; m0 < M; m0 += kGemvMaxT) {
-      const int mc = (M - m0 < kGemvMaxT) ? M - m0 : kGemvMaxT;
+    for (int m0 = 0; m0 < M; m0 += cap) {
+      const int mc = (M - m0 < cap) ? M - m0 : cap;
       void* lo = logits_out ? static_cast<char*>(logits_out) + (static_cast<size_t>(b0) * M + m0) * V * esz : nullptr;
       if (int rc = forward_pass(m, tokens + m0, tok_stride, pos_base, pos_off + m0, row0, b0, 1, mc,
                                 ids_out ? ids_out + m0 : nullptr, ids_stride, lo, logits_dtype, V, skip_head, st))
@@ -293,6 +295,22 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
       SD_REQUIRE(false, "model_create: layer %d has NULL weights", l);
     }
   }
+  {
+    // 64-token passes need every matrix of the model to be a shape gemm_skinny.hip covers
+    const sd_model_config& c = m->cfg;
+    const bool llama = (c.arch == SD_ARCH_LLAMA);
+    const int HqD = c.n_heads * c.head_dim;
+    const bool ok = gemm_skinny_covers(kSkinnyMaxT, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model) &&
+                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, HqD) &&
+                    gemm_skinny_covers(kSkinnyMaxT, llama ? c.d_ff : c.d_ff / 2, c.d_model) &&
+                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, c.d_ff) &&
+                    gemm_skinny_covers(kSkinnyMaxT, (c.vocab + 1) / 2, c.d_model);
+    const char* env = getenv("SPECDEC_MAX_PASS_TOKENS");  // testing knob: 9 forces the small-T kernel everywhere
+    int want = env ? atoi(env) : kSkinnyMaxT;
+    if (want < kGemvMaxT) want = kGemvMaxT;
+    if (want > kSkinnyMaxT) want = kSkinnyMaxT;
+    m->max_t = ok ? want : kGemvMaxT;
+  }
   if (cfg->packed) {
     const char* base = static_cast<const char*>(cfg->packed);
     for (int i = 0; i <= 4 * cfg->n_layers; ++i) m->packed.push_back(base + packed_offset(m->cfg, i));
@@ -305,6 +323,8 @@ extern "C" int sd_model_destroy(sd_model* m) {
   delete m;
   return 0;
 }
+
+extern "C" int sd_model_pass_tokens(const sd_model* m) { return m ? m->max_t : 0; }
 
 extern "C" size_t sd_model_workspace_bytes(const sd_model* m) { return m ? workspace_bytes(m->cfg) : 0; }
 
@@ -326,7 +346,7 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->B = B;
   m->Lmax = Lmax;
   const sd_model_config& c = m->cfg;
-  const size_t T = kGemvMaxT;
+  const size_t T = kSkinnyMaxT;
   char* p = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   m->x = reinterpret_cast<uint16_t*>(p);
   p += align_up(T * c.d_model * 2, 256);
@@ -357,7 +377,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
                                    double* bytes_per_launch) {
   clear_error();
   SD_REQUIRE(m && m->x && avg_usec && bytes_per_launch, "probe_gemv: NULL argument / model not bound");
-  SD_REQUIRE(T >= 1 && T <= kGemvMaxT && iters >= 1, "probe_gemv: T=%d iters=%d", T, iters);
+  SD_REQUIRE(T >= 1 && T <= kSkinnyMaxT && iters >= 1, "probe_gemv: T=%d iters=%d", T, iters);
   const sd_model_config& c = m->cfg;
   const bool llama = (c.arch == SD_ARCH_LLAMA);
   const int d = c.d_model, ff = c.d_ff, Hq = c.n_heads, D = c.head_dim;

@@ -1,0 +1,353 @@
+// Weight-streaming skinny GEMM for 10..64 tokens: batched verify (B rows x (K+1) positions)
+// and chunked prefill on gfx950.
+//
+// Same contract, weight layout (row-major or csrc/pack.hip tile streams), work split
+// (gemv_geometry) and fused epilogues as gemv.hip, which covers T <= 9. What changes with T:
+//   * the token columns no longer fit one MFMA tile: a wave keeps TG = ceil(T/16) accumulators
+//     and runs TG MFMAs per 1-KiB weight fragment (the fragment is loaded once);
+//   * the activations no longer fit LDS (64 tokens x 8192 x 2 B = 1 MiB): K is walked in
+//     contiguous CHUNKS of kc <= 2048 columns. A chunk of all T rows is staged (normalised) into
+//     LDS by the whole workgroup, every wave multiplies its sc = kc / (32 ksplit) steps of it,
+//     and the next chunk replaces it;
+//   * the norm statistics need whole rows before the first chunk: a prologue pass reads x once
+//     (rows split over the 16 waves) while the first weight batch is in flight.
+// The weight stream is decoupled from the chunks: every wave keeps a double buffer of 8-step
+// batches in flight (16 KiB per wave, 256 KiB per CU) and crosses chunk boundaries inside a
+// batch. The reference has no such kernel: its verify is K sequential HF forwards per row
+// (speculative_scheduler.py:192-199) and its prefill is HF's.
+
+#include "gemv_device.h"
+
+namespace sd {
+
+constexpr int kSkBatch = 4;       // weight steps per batch (two batches in flight)
+constexpr int kSkMaxKc = 2048;
+
+struct SkinnyGeom {
+  int kc;        // chunk width in columns: power of two, multiple of 32*ksplit, divides K
+  int sc_shift;  // log2(steps per wave per chunk)
+};
+
+static __host__ __device__ size_t skinny_x_bytes(int T, int kc) { return (static_cast<size_t>(T) * (kc + kXPad) * 2 + 15) & ~static_cast<size_t>(15); }
+static __host__ __device__ size_t skinny_part_bytes(int TG) { return sizeof(float) * kGemvWaves * TG * 256; }
+static size_t skinny_smem(int T, int TG, int kc) {
+  const size_t xs = skinny_x_bytes(T, kc), part = skinny_part_bytes(TG);
+  return (xs > part ? xs : part) + sizeof(float) * 2 * kSkinnyMaxT;
+}
+
+// chunk width for (T, K, ksplit), or 0 when the shape is not covered
+static int skinny_chunk(int T, int K, int ksplit, int kw) {
+  if (K % 32 != 0 || kw * ksplit != K) return 0;
+  const int TG = (T + 15) / 16;
+  int best = 0;
+  for (int kc = 32 * ksplit; kc <= kSkMaxKc; kc <<= 1) {
+    if (K % kc != 0) break;
+    if (skinny_smem(T, TG, kc) > 160 * 1024) break;
+    best = kc;
+  }
+  return best;
+}
+
+template <int EPI, int TG>
+__global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArgs a, const SkinnyGeom sg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = a.K, T = a.T;
+  const int kc = sg.kc, KP = kc + kXPad;
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem);                    // [T][kc + pad] bf16, one chunk
+  float* part = reinterpret_cast<float*>(smem);                       // aliases xs: [16 waves][TG][16][16]
+  const size_t xs_bytes = skinny_x_bytes(T, kc), part_bytes = skinny_part_bytes(TG);
+  float* stat = reinterpret_cast<float*>(smem + (xs_bytes > part_bytes ? xs_bytes : part_bytes));  // [T][2] mean, rstd
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int ksplit = a.ksplit;
+  const int tiles_per_round = kGemvWaves / ksplit;
+  const int kpart = wave & (ksplit - 1);
+  const int tslot = wave / ksplit;
+  const int steps_w = a.kw >> 5;                 // steps of one wave over the whole K
+  const int sc_shift = sg.sc_shift, sc = 1 << sc_shift;
+  const uint16_t* W = static_cast<const uint16_t*>(a.W);
+
+  const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
+  const int p_hi = min(p_lo + a.ppw, a.n_pairs);
+  const int tile_pairs = a.tile_pairs;
+  const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;
+  const int rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
+
+  // address of a lane's A fragment of global step gs (k = 32 gs): tile start + gs * wstride + lane_off
+  int wstride = 32;
+  unsigned lane_off = 0;
+  auto tile_start = [&](int tile) -> const uint16_t* {
+    const int p0 = p_lo + tile * tile_pairs;
+    if (a.packed) {
+      int np = min(tile_pairs, p_hi - p0);
+      if (np < 1) np = 1;
+      int jp = n & 7, second = n >> 3;
+      if (jp >= np) { jp = 0; second = 0; }
+      wstride = np * 64;
+      lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
+      return W + static_cast<size_t>(p0) * 2 * K;
+    }
+    int p = p0 + (n & 7);
+    int second = n >> 3;
+    if ((n & 7) >= tile_pairs || p >= p_hi) { p = min(p0, p_hi - 1); second = 0; }
+    int r0, r1;
+    pair_rows<EPI>(a, p, r0, r1);
+    int r = second ? r1 : r0;
+    if (r >= a.N) r = r0;
+    wstride = 32;
+    lane_off = static_cast<unsigned>(r) * static_cast<unsigned>(K) + static_cast<unsigned>(g * 8);
+    return W;
+  };
+  // wave-local step s (chunk-major) -> global step
+  auto gstep = [&](int s) { return ((s >> sc_shift) * ksplit + kpart) * sc + (s & (sc - 1)); };
+
+  u32x4 bufA[kSkBatch], bufB[kSkBatch];
+  auto issue = [&](u32x4 (&buf)[kSkBatch], const uint16_t* ts, int s0) {
+#pragma unroll
+    for (int j = 0; j < kSkBatch; ++j) {
+      const int s = s0 + j;
+      if (s < steps_w) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ts + static_cast<size_t>(gstep(s)) * wstride + lane_off));
+    }
+  };
+
+  // ---- weights of round 0 first, then the norm statistics under their latency
+  const uint16_t* ts0 = tile_start(tslot < n_tiles ? tslot : 0);
+  if (tslot < n_tiles) issue(bufA, ts0, 0);
+
+  const uint16_t* xin = static_cast<const uint16_t*>(a.x);
+  if (a.prologue != PRO_NONE) {
+    const int nvec = K >> 3;
+    const float invK = 1.0f / static_cast<float>(K);
+    for (int t = wave; t < T; t += kGemvWaves) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t) * a.x_stride);
+      float s1 = 0.f, s2 = 0.f;
+      for (int v = lane; v < nvec; v += kWave) {
+        const u32x4 q = src[v];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(q[j] << 16), hi = __uint_as_float(q[j] & 0xffff0000u);
+          s1 += lo + hi;
+          s2 += lo * lo + hi * hi;
+        }
+      }
+      s1 = wave_reduce_sum(s1);
+      s2 = wave_reduce_sum(s2);
+      if (lane == 0) {
+        if (a.prologue == PRO_RMSNORM) {
+          stat[2 * t] = 0.f;
+          stat[2 * t + 1] = rsqrtf(s2 * invK + a.norm_eps);
+        } else {
+          const float mean = s1 * invK;
+          stat[2 * t] = mean;
+          stat[2 * t + 1] = rsqrtf(fmaxf(s2 * invK - mean * mean, 0.f) + a.norm_eps);
+        }
+      }
+    }
+  }
+  // (the first chunk boundary's barrier publishes stat[])
+
+  // ---- staging of chunk c: thread -> fixed 8-column block kv, tokens t0, t0 + tpi, ...
+  const int kvec = kc >> 3;                 // power of two <= 256
+  const int kv = tid & (kvec - 1);
+  const int t0 = tid / kvec, tpi = kGemvThreads / kvec;
+  auto stage = [&](int c) {
+    const int col = c * kc + kv * 8;
+    u32x4 nw4 = {0u, 0u, 0u, 0u}, nb4 = {0u, 0u, 0u, 0u};
+    if (a.prologue != PRO_NONE) {
+      nw4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + col);
+      if (a.prologue == PRO_LAYERNORM) nb4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_b) + col);
+    }
+    for (int t = t0; t < T; t += tpi) {
+      u32x4 q = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t) * a.x_stride + col);
+      if (a.prologue == PRO_RMSNORM) {
+        // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
+        const float rs = stat[2 * t + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(q[j] << 16) * rs));
+          const float x1 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(q[j] & 0xffff0000u) * rs));
+          q[j] = static_cast<uint32_t>(float_to_bf16_bits(x0 * __uint_as_float(nw4[j] << 16))) |
+                 (static_cast<uint32_t>(float_to_bf16_bits(x1 * __uint_as_float(nw4[j] & 0xffff0000u))) << 16);
+        }
+      } else if (a.prologue == PRO_LAYERNORM) {
+        const float mean = stat[2 * t], rs = stat[2 * t + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y0 = (__uint_as_float(q[j] << 16) - mean) * rs * __uint_as_float(nw4[j] << 16) + __uint_as_float(nb4[j] << 16);
+          const float y1 = (__uint_as_float(q[j] & 0xffff0000u) - mean) * rs * __uint_as_float(nw4[j] & 0xffff0000u) +
+                           __uint_as_float(nb4[j] & 0xffff0000u);
+          q[j] = static_cast<uint32_t>(float_to_bf16_bits(y0)) | (static_cast<uint32_t>(float_to_bf16_bits(y1)) << 16);
+        }
+      }
+      *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + kv * 8) = q;
+    }
+  };
+
+  float best_v[TG];
+  int best_i[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) { best_v[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+
+  // B fragment rows of this lane: token 16 grp + n (columns >= T read row T-1; never used)
+  int xrow_off[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    const int t = 16 * q + n;
+    xrow_off[q] = (t < T ? t : T - 1) * KP + kpart * sc * 32 + g * 8;
+  }
+
+  for (int r = 0; r < rounds; ++r) {
+    const int tile = r * tiles_per_round + tslot;
+    const bool valid = tile < n_tiles;
+    const uint16_t* ts = (r == 0) ? ts0 : tile_start(valid ? tile : 0);
+    if (r != 0 && valid) issue(bufA, ts, 0);
+    f32x4_t acc[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto consume = [&](u32x4 (&buf)[kSkBatch], int s0) {
+#pragma unroll
+      for (int j = 0; j < kSkBatch; ++j) {
+        const int s = s0 + j;
+        if (s < steps_w) {                       // workgroup-uniform
+          if ((s & (sc - 1)) == 0) {             // chunk boundary: replace the staged chunk
+            __syncthreads();                     // every wave is done with the previous chunk (or partials)
+            stage(s >> sc_shift);
+            __syncthreads();
+          }
+          if (valid) {
+            const int koff = (s & (sc - 1)) * 32;
+#pragma unroll
+            for (int q = 0; q < TG; ++q) {
+              const u32x4 xb = *reinterpret_cast<const u32x4*>(xs + xrow_off[q] + koff);
+              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
+                                                               __builtin_bit_cast(bf16x8_t, xb), acc[q], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    for (int s0 = 0; s0 < steps_w; s0 += 2 * kSkBatch) {
+      if (valid) issue(bufB, ts, s0 + kSkBatch);
+      consume(bufA, s0);
+      if (valid) issue(bufA, ts, s0 + 2 * kSkBatch);
+      consume(bufB, s0 + kSkBatch);
+    }
+
+    // K-slice partials through LDS (aliasing the chunk buffer)
+    __syncthreads();
+    float* slot = part + static_cast<size_t>(wave) * TG * 256;
+#pragma unroll
+    for (int q = 0; q < TG; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slot[q * 256 + (4 * g + e) * 16 + n] = acc[q][e];
+    __syncthreads();
+    for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
+      const int tsl = it >> 7, jp = (it >> 4) & 7, tl = it & 15;  // tl == tid & 15 on every trip
+      const int etile = r * tiles_per_round + tsl;
+      const int p = p_lo + etile * tile_pairs + jp;
+      if (etile < n_tiles && jp < tile_pairs && p < p_hi) {
+        int r0, r1;
+        pair_rows<EPI>(a, p, r0, r1);
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+          const int t = 16 * q + tl;
+          if (t < T) {
+            const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
+            float y0 = 0.f, y1 = 0.f;
+            for (int w = 0; w < ksplit; ++w) {
+              y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
+              y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
+            }
+            epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
+          }
+        }
+      }
+    }
+    // the next round's first chunk boundary (or the fold below) starts with a barrier
+  }
+
+  if constexpr (EPI == EPI_ARGMAX) {
+    // thread tid holds a running best for tokens 16 q + (tid & 15): fold the 64 candidates per token
+    __syncthreads();
+    float* sv = part;                                              // [16 TG tokens][64]
+    int* si = reinterpret_cast<int*>(part + 16 * TG * 64);
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      sv[(16 * q + (tid & 15)) * 64 + (tid >> 4)] = best_v[q];
+      si[(16 * q + (tid & 15)) * 64 + (tid >> 4)] = best_i[q];
+    }
+    __syncthreads();
+    for (int t = wave; t < T; t += kGemvWaves) {
+      float bv = sv[t * 64 + lane];
+      int bi = si[t * 64 + lane];
+      wave_reduce_argmax(bv, bi);
+      if (lane == 0) {
+        a.part_val[static_cast<size_t>(t) * gridDim.x + blockIdx.x] = bv;
+        a.part_idx[static_cast<size_t>(t) * gridDim.x + blockIdx.x] = bi;
+      }
+    }
+  }
+}
+
+template <int EPI, int TG>
+static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int EPI>
+static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
+  switch ((a.T + 15) / 16) {
+    case 1: return launch_skinny_one<EPI, 1>(a, sg, grid, smem, st);
+    case 2: return launch_skinny_one<EPI, 2>(a, sg, grid, smem, st);
+    case 3: return launch_skinny_one<EPI, 3>(a, sg, grid, smem, st);
+    default: return launch_skinny_one<EPI, 4>(a, sg, grid, smem, st);
+  }
+}
+
+bool gemm_skinny_covers(int T, int n_pairs, int K) {
+  if (T < 1 || T > kSkinnyMaxT || n_pairs < 1) return false;
+  const GemvGeom q = gemv_geometry(n_pairs, K);
+  return skinny_chunk(T, K, q.ksplit, q.kw) != 0;
+}
+
+int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
+  GemvArgs a = a_in;
+  SD_REQUIRE(a.T >= 1 && a.T <= kSkinnyMaxT, "gemm_skinny: T=%d out of range 1..%d", a.T, kSkinnyMaxT);
+  SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemm_skinny: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
+  SD_REQUIRE(a.n_pairs > 0, "gemm_skinny: no rows");
+  const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
+  a.ppw = q.ppw;
+  a.tile_pairs = q.tile_pairs;
+  a.ksplit = q.ksplit;
+  a.kw = q.kw;
+  SkinnyGeom sg{};
+  sg.kc = skinny_chunk(a.T, a.K, q.ksplit, q.kw);
+  SD_REQUIRE(sg.kc != 0, "gemm_skinny: shape T=%d K=%d (ksplit %d) is not covered", a.T, a.K, q.ksplit);
+  const int sc = sg.kc / (32 * q.ksplit);
+  sg.sc_shift = 0;
+  while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
+  const int TG = (a.T + 15) / 16;
+  const size_t smem = skinny_smem(a.T, TG, sg.kc);
+  switch (epi) {
+    case EPI_QKV_ROPE: return launch_skinny_epi<EPI_QKV_ROPE>(a, sg, q.grid, smem, st);
+    case EPI_RESID: return launch_skinny_epi<EPI_RESID>(a, sg, q.grid, smem, st);
+    case EPI_SWIGLU: return launch_skinny_epi<EPI_SWIGLU>(a, sg, q.grid, smem, st);
+    case EPI_GELU: return launch_skinny_epi<EPI_GELU>(a, sg, q.grid, smem, st);
+    case EPI_ARGMAX: return launch_skinny_epi<EPI_ARGMAX>(a, sg, q.grid, smem, st);
+    default: SD_REQUIRE(false, "gemm_skinny: unknown epilogue %d", epi);
+  }
+  return 0;
+}
+
+}  // namespace sd

@@ -34,43 +34,12 @@
 //     residual / logits stores. Rows 0..7 of a tile are the first rows of its
 //     pairs, rows 8..15 the second rows.
 
-#include "kernels.h"
+#include "gemv_device.h"
 
 namespace sd {
 
-constexpr int kGemvThreads = 1024;
-constexpr int kGemvWaves = kGemvThreads / kWave;  // 16 waves: 4 per SIMD
 constexpr int kBatch = 12;                        // loads in flight per lane
 constexpr int kPre = 8;                           // of which issued before the prologue
-
-constexpr int kXPad = 8;                          // bf16 elements of padding per staged x row
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float gelu_new(float x) {
-  // GPT-2 "gelu_new": 0.5 x (1 + tanh( sqrt(2/pi) (x + 0.044715 x^3) ))
-  const float c = 0.7978845608028654f;
-  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
-}
-
-// row indices of pair p for each epilogue
-template <int EPI>
-__device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int& r1) {
-  if constexpr (EPI == EPI_QKV_ROPE) {
-    const int half = a.head_dim >> 1;
-    const int h = p / half, i = p - h * half;
-    r0 = h * a.head_dim + i;
-    r1 = r0 + half;
-  } else if constexpr (EPI == EPI_SWIGLU) {
-    r0 = p;
-    r1 = p + a.n_pairs;  // up rows follow the gate rows
-  } else {
-    r0 = 2 * p;
-    r1 = 2 * p + 1;
-  }
-}
 
 // ------------------------------------------------------------------------------
 // staging of x into LDS (bf16 [T][K + pad]) with the fused normalisation
@@ -150,93 +119,6 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
     }
   }
   __syncthreads();
-}
-
-// ------------------------------------------------------------------------------
-// epilogues: one lane finishes token t of pair p (y0 = row r0, y1 = row r1)
-// ------------------------------------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
-                                         float y1, float& best_v, int& best_i, bool have_old = false,
-                                         uint32_t old_pre = 0) {
-  const int b = t / a.M, m = t - b * a.M;
-  if constexpr (EPI == EPI_QKV_ROPE) {
-    if (a.bias) {
-      const uint16_t* bs = static_cast<const uint16_t*>(a.bias);
-      y0 += bf16_bits_to_float(bs[r0]);
-      y1 += bf16_bits_to_float(bs[r1]);
-    }
-    const int D = a.head_dim, half = D >> 1;
-    const int h = p / half, i = p - h * half;
-    const int pos = a.pos_base[b] + a.pos_off + m;
-    float o0 = y0, o1 = y1;
-    if (a.rope_cos && h < a.n_q_heads + a.n_kv_heads && pos >= 0 && pos < a.max_pos) {
-      const float c = a.rope_cos[static_cast<size_t>(pos) * half + i];
-      const float s = a.rope_sin[static_cast<size_t>(pos) * half + i];
-      o0 = y0 * c - y1 * s;
-      o1 = y1 * c + y0 * s;
-    }
-    const uint16_t u0 = float_to_bf16_bits(o0), u1 = float_to_bf16_bits(o1);
-    if (h < a.n_q_heads) {
-      uint16_t* q = static_cast<uint16_t*>(a.out) + static_cast<size_t>(t) * a.out_stride + h * D + i;
-      q[0] = u0;
-      q[half] = u1;
-    } else if (pos >= 0 && pos < a.l_max) {
-      // in-place KV append (the fused form of kv_append_ref, reference.py:59-93):
-      // K rows are [Lmax][D], V is kept transposed [D][Lmax] (see attention.hip)
-      const bool is_k = h < a.n_q_heads + a.n_kv_heads;
-      if (is_k) {
-        const int kvh = h - a.n_q_heads;
-        uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max + pos) * D + i;
-        dst[0] = u0;
-        dst[half] = u1;
-      } else {
-        const int kvh = h - a.n_q_heads - a.n_kv_heads;
-        uint16_t* dst = static_cast<uint16_t*>(a.v_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * D + i) * a.l_max + pos;
-        dst[0] = u0;
-        dst[static_cast<size_t>(half) * a.l_max] = u1;
-      }
-    }
-  } else if constexpr (EPI == EPI_RESID) {
-    if (a.bias) {
-      const uint16_t* bs = static_cast<const uint16_t*>(a.bias);
-      y0 += bf16_bits_to_float(bs[r0]);
-      y1 += bf16_bits_to_float(bs[r1]);
-    }
-    uint32_t* px = reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(a.out) + static_cast<size_t>(t) * a.out_stride + r0);
-    const uint32_t old = have_old ? old_pre : *px;  // prefetched at kernel entry when possible
-    const float n0 = __uint_as_float(old << 16) + y0;
-    const float n1 = __uint_as_float(old & 0xffff0000u) + y1;
-    *px = static_cast<uint32_t>(float_to_bf16_bits(n0)) | (static_cast<uint32_t>(float_to_bf16_bits(n1)) << 16);
-  } else if constexpr (EPI == EPI_SWIGLU) {
-    const float g = y0, u = y1;
-    const float act = g / (1.0f + __expf(-g)) * u;
-    static_cast<uint16_t*>(a.out)[static_cast<size_t>(t) * a.out_stride + p] = float_to_bf16_bits(act);
-  } else if constexpr (EPI == EPI_GELU) {
-    const uint16_t* bs = static_cast<const uint16_t*>(a.bias);
-    if (bs) {
-      y0 += bf16_bits_to_float(bs[r0]);
-      y1 += bf16_bits_to_float(bs[r1]);
-    }
-    uint32_t* po = reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(a.out) + static_cast<size_t>(t) * a.out_stride + r0);
-    *po = static_cast<uint32_t>(float_to_bf16_bits(gelu_new(y0))) | (static_cast<uint32_t>(float_to_bf16_bits(gelu_new(y1))) << 16);
-  } else {  // EPI_ARGMAX: logits are the bf16-rounded products, as a bf16 lm_head returns
-    const uint16_t u0 = float_to_bf16_bits(y0), u1 = float_to_bf16_bits(y1);
-    const float f0 = bf16_bits_to_float(u0), f1 = bf16_bits_to_float(u1);
-    if (argmax_better(f0, r0, best_v, best_i)) { best_v = f0; best_i = r0; }
-    if (r1 < a.N && argmax_better(f1, r1, best_v, best_i)) { best_v = f1; best_i = r1; }
-    if (a.out) {
-      if (a.out_dtype == SD_F32) {
-        float* lo = static_cast<float*>(a.out) + static_cast<size_t>(t) * a.out_stride;
-        lo[r0] = f0;
-        if (r1 < a.N) lo[r1] = f1;
-      } else {
-        uint16_t* lo = static_cast<uint16_t*>(a.out) + static_cast<size_t>(t) * a.out_stride;
-        lo[r0] = u0;
-        if (r1 < a.N) lo[r1] = u1;
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------
@@ -577,6 +459,7 @@ static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipSt
 }
 
 int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
+  if (a_in.T > kGemvMaxT) return launch_gemm_skinny(a_in, epi, st);
   GemvArgs a = a_in;
   SD_REQUIRE(a.T >= 1 && a.T <= kGemvMaxT, "gemv: T=%d out of range 1..%d", a.T, kGemvMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemv: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);

@@ -11,7 +11,8 @@ namespace sd {
 enum GemvPrologue { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };
 enum GemvEpilogue { EPI_QKV_ROPE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_ARGMAX = 4 };
 
-constexpr int kGemvMaxT = 9;  // tokens per pass (K+1 for K = 8)
+constexpr int kGemvMaxT = 9;     // tokens per launch of gemv.hip (K+1 for K = 8)
+constexpr int kSkinnyMaxT = 64;  // tokens per launch of gemm_skinny.hip (batched verify, chunked prefill)
 
 struct GemvArgs {
   // weights: bf16 [N][K] row-major
@@ -64,7 +65,9 @@ GemvGeom gemv_geometry(int n_pairs, int K);
 size_t packed_matrix_bytes(int n_pairs, int K);
 size_t packed_offset(const sd_model_config& c, int index);  // index: 4*layer + {0 qkv,1 out,2 up,3 down}; 4*n_layers = lm_head
 int gemv_grid(const GemvArgs& a, int* ppw_out);
-int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);
+int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip
+int launch_gemm_skinny(const GemvArgs& a, int epi, hipStream_t st);   // T <= 64
+bool gemm_skinny_covers(int T, int n_pairs, int K);                  // shape handled by gemm_skinny.hip
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------
 struct AttnArgs {

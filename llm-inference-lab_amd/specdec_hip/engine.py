@@ -135,6 +135,11 @@ class HipModel:
         _abi.check(rc, "sd_model_forward")
         return ids, logits
 
+    @property
+    def pass_tokens(self) -> int:
+        """Tokens per forward pass (64 with the multi-token kernel, else 9)."""
+        return int(self.lib.sd_model_pass_tokens(self.handle))
+
     PROBE_O, PROBE_GATE_UP, PROBE_DOWN, PROBE_LM_HEAD = 1, 2, 3, 4
 
     def probe_gemv(self, which: int, T: int, iters: int = 200, stream: Optional[torch.cuda.Stream] = None):

@@ -102,3 +102,66 @@ def test_forward_errors_are_loud():
     hm = _hip_model(tgt, batch=1, l_max=16)
     with pytest.raises(_abi.HipLibraryError, match="exceeds bound batch"):
         hm.forward(torch.zeros((2, 1), dtype=torch.int32, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"))
+
+
+def _forward_all(mw, toks, env_cap, monkeypatch, l_max=160):
+    """One forward over toks [B][L] from empty caches; env_cap = tokens per pass."""
+    if env_cap is None:
+        monkeypatch.delenv("SPECDEC_MAX_PASS_TOKENS", raising=False)
+    else:
+        monkeypatch.setenv("SPECDEC_MAX_PASS_TOKENS", str(env_cap))
+    hm = _hip_model(mw, batch=toks.shape[0], l_max=l_max)
+    assert hm.pass_tokens == (64 if env_cap is None else env_cap)   # the multi-token kernel covers these shapes
+    pos0 = torch.zeros(toks.shape[0], dtype=torch.int32, device="cuda")
+    ids, logits = hm.forward(toks.to(torch.int32).cuda(), pos0, 0, want_logits=True)
+    torch.cuda.synchronize()
+    return ids.cpu().long(), logits.float().cpu()
+
+
+@pytest.mark.parametrize("name,B,L", [("llama", 1, 64), ("llama", 1, 100), ("llama", 2, 20), ("gpt2", 1, 50), ("gpt2", 3, 17)])
+def test_multi_token_pass_matches_oracle_and_small_pass(name, B, L, monkeypatch):
+    """10..64 tokens per pass (gemm_skinny.hip: chunked prefill, batched verify) on HF-initialised
+    weights: logits within the bf16 forward tolerance of the oracle, fused argmax == argmax of the
+    stored logits, and the same forward done in 9-token passes (gemv.hip) gives the same logits up
+    to accumulation order (a few bf16 ulps: 1 % of the logit range)."""
+    mw, toks, _ = load_hf_golden(name, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(L * 7 + B)
+    toks = torch.randint(0, mw.config.vocab, (B, L), generator=g)
+    want, _ = OracleLM(mw, precision="bf16").forward(toks)
+    ids64, lg64 = _forward_all(mw, toks, None, monkeypatch)
+    ids9, lg9 = _forward_all(mw, toks, 9, monkeypatch)
+    assert _rel_err(lg64, want) < 0.03, _rel_err(lg64, want)
+    assert torch.equal(ids64, lg64.argmax(-1))
+    assert _rel_err(lg64, lg9) < 0.01, _rel_err(lg64, lg9)
+    assert (ids64 == ids9).float().mean().item() > 0.97
+
+
+@pytest.mark.parametrize("B,M", [(8, 5), (4, 9), (7, 9), (2, 5), (3, 16), (1, 33), (1, 64)])
+def test_batched_verify_shapes_on_synthetic_pair(B, M, monkeypatch):
+    """BASELINE config 3/4 shapes (B rows x K+1 positions in ONE pass) on the synthetic tiny pair, rows
+    at different cache lengths: token ids identical to the oracle (large margins by construction) and
+    to the 9-token-pass path."""
+    drf, tgt = tiny_pair()
+    V = tgt.config.vocab
+    lm = OracleLM(tgt, precision="bf16")
+    lens = [3 + 5 * b for b in range(B)]
+    g = torch.Generator().manual_seed(B * 100 + M)
+    seqs = [torch.randint(4, V, (n + M,), generator=g) for n in lens]
+    outs = {}
+    for cap in (None, 9):
+        if cap is None:
+            monkeypatch.delenv("SPECDEC_MAX_PASS_TOKENS", raising=False)
+        else:
+            monkeypatch.setenv("SPECDEC_MAX_PASS_TOKENS", str(cap))
+        hm = _hip_model(tgt, batch=B, l_max=128)
+        assert hm.pass_tokens == (64 if cap is None else 9)
+        for b, (n, s) in enumerate(zip(lens, seqs)):
+            hm.forward(s[:n].to(torch.int32).view(1, -1).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), 0,
+                       skip_head=True, row0=b)
+        new = torch.stack([s[n:] for n, s in zip(lens, seqs)], 0)
+        ids, _ = hm.forward(new.to(torch.int32).cuda(), torch.tensor(lens, dtype=torch.int32, device="cuda"), 0)
+        outs[cap] = ids.cpu().long()
+    for b, s in enumerate(seqs):
+        want, _ = lm.forward(s.view(1, -1))
+        assert torch.equal(outs[None][b], want[0, lens[b]:].argmax(-1)), (B, M, b)
+    assert torch.equal(outs[None], outs[9])
