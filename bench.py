@@ -213,7 +213,9 @@ def main():
         st = torch.cuda.Stream()
         usec, nbytes = tm.probe_gemv(tm.PROBE_GATE_UP, T=min(B * (K + 1), tm.pass_tokens), iters=280, stream=st)
         ach = nbytes / (usec * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "gemv_mfma_kernel<EPI_SWIGLU> (target norm+gate/up+SwiGLU)",
+        Tp = min(B * (K + 1), tm.pass_tokens)
+        kname = "gemv_mfma_kernel<EPI_SWIGLU>" if Tp <= 9 else f"gemm_skinny_kernel<EPI_SWIGLU, {(Tp + 15) // 16}>"
+        out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (target norm+gate/up+SwiGLU, {Tp} tokens)",
                            "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK_BPS,
                            "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": usec}
         # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
