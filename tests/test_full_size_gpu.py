@@ -1,0 +1,83 @@
+"""BASELINE.json's full sizes (Llama-3.2-3B target + 1B draft, bf16) through size-independent properties —
+the CPU oracle cannot run these shapes in test time (bench.py's cpu_baseline leg re-checks a bounded sample).
+
+Property (greedy speculative decoding): whatever the draft proposes, the emitted sequence is the target's
+own greedy continuation; with the bonus rule of generate_batch every step emits accept_len + 1 of them.
+So the pipeline's tokens must equal those of the SAME target decoded one token at a time through
+`generate_tokens` (M = 1 forwards: another kernel path — 1-token GEMV passes vs 5/40-token verify passes),
+at batch 1 (config 2) and batch 8 (config 3), for every K."""
+
+import pytest
+import torch
+
+from helpers import synthetic_prompts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_pair():
+    from specdec_hip import weights as W
+    from src.specdec import HipLM
+
+    tgt = W.synthetic_llama(W.LLAMA_3_2_3B, seed=0, device="cuda")
+    drf = W.synthetic_llama(W.LLAMA_3_2_1B, seed=1, device="cuda", embed_from=tgt, flip_fraction=0.2)
+    return HipLM(drf), HipLM(tgt)
+
+
+def _reference_greedy(target_lm, prompts, n):
+    out = []
+    for p in prompts:
+        ids, _ = target_lm.generate_tokens(torch.tensor([p]), n, do_sample=False)
+        out.append(ids[0].tolist())
+    return out
+
+
+@pytest.mark.parametrize("k,batch", [(4, 1), (4, 8), (1, 8), (8, 8), (2, 3)])
+def test_specdec_output_is_the_targets_greedy_continuation(full_pair, k, batch):
+    from src.specdec import SpeculativePipeline
+
+    draft_lm, target_lm = full_pair
+    V = target_lm.vocab_size
+    prompts = synthetic_prompts(batch, 32, V).tolist()
+    n = 40
+    pipe = SpeculativePipeline(base_lm=target_lm, draft_lm=draft_lm, controller="fixed", controller_params={"k": k}, seed=1234)
+    got = pipe.generate_batch(prompts, max_tokens=n, do_sample=False)
+    want = _reference_greedy(target_lm, prompts[: min(batch, 3)], n + k + 1)
+    for b, w in enumerate(want):
+        g = got[b]["generated_tokens"]
+        assert len(g) >= n
+        assert g == w[: len(g)], (k, batch, b)
+    for r in got:
+        # counters: every step proposes k and emits accept_len + 1 tokens (bonus counted, pipeline.py:3433)
+        steps = r["batch_metrics"]["total_steps"]
+        assert r["proposed"] % k == 0 and r["proposed"] // k <= steps
+        assert r["accepted"] == len(r["generated_tokens"])
+        assert r["proposed"] // k <= r["accepted"] <= (k + 1) * (r["proposed"] // k)
+    acc = sum(r["accepted"] for r in got) / sum(r["proposed"] for r in got)
+    assert acc > 1.0 / k   # the draft shares 80 % of the successors: more than the bonus token alone is accepted
+    # rows are independent: row 1 of the batch equals the same prompt decoded alone
+    if batch > 1:
+        alone = pipe.generate_batch([prompts[1]], max_tokens=n, do_sample=False)[0]
+        assert alone["generated_tokens"] == got[1]["generated_tokens"]
+
+
+def test_kv_append_is_position_exact_at_full_size(full_pair):
+    """Round trip through the fused in-place KV append: decoding 24 tokens one by one, then re-prefilling
+    the same 24 tokens in one multi-token pass into another cache row-set, must give the same next token
+    and the same logits up to accumulation order (1 % of the range) — the cache written by 1-token passes
+    and by a 24-token pass is interchangeable."""
+    _, target_lm = full_pair
+    V = target_lm.vocab_size
+    prompt = synthetic_prompts(1, 16, V)[0].tolist()
+    ids, logits = target_lm.generate_tokens(torch.tensor([prompt]), 24, do_sample=False)
+    seq = prompt + ids[0].tolist()
+    eng = target_lm.new_engine(1, 128)
+    toks = torch.tensor([seq[:-1]], dtype=torch.int32, device="cuda")
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got_ids, got_logits = eng.forward(toks, zero, 0, want_logits=True)
+    assert eng.pass_tokens == 64
+    # position i of the one-pass prefill predicts seq[i+1]
+    assert got_ids[0, len(prompt) - 1:].cpu().tolist() == seq[len(prompt):]
+    a, b = got_logits[0, -1].float().cpu(), logits[0, -1].float().cpu()
+    assert (a - b).abs().max().item() / b.abs().max().item() < 0.01
