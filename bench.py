@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--flip", type=float, default=0.2, help="fraction of tokens whose draft successor differs")
     ap.add_argument("--cpu-baseline-steps", type=int, default=6, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: both models stream an OCP e4m3 copy of their Linear weights (per-row scales, bf16 activations and "
+                         "MFMA); not the headline configuration (BASELINE config 2 is bf16), CPU parity leg uses the dequantised weights")
     ap.add_argument("--do-sample", action="store_true",
                     help="sampled bonus token (T=0.7, top_k=50, top_p=0.9: the reference's default sampler) instead of greedy; "
                          "not the headline configuration (SPECDEC_DETERMINISTIC is greedy), no CPU parity leg")
@@ -87,7 +90,7 @@ def prompts_for(rank, batch, vocab):
     return out
 
 
-def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows):
+def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows, weight_dtype="bf16"):
     """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample.
     Returns the baseline dict and whether the GPU emitted the same tokens on those steps."""
     from oracle.model_ref import OracleLM
@@ -103,6 +106,10 @@ def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows):
     torch.set_num_threads(cores)
     log(f"cpu_baseline: {cores} threads, copying weights to the host")
     d_cpu, t_cpu = drf.to("cpu"), tgt.to("cpu")
+    if weight_dtype == "fp8":
+        from oracle import fp8_ref
+
+        d_cpu, t_cpu = fp8_ref.dequantized(d_cpu), fp8_ref.dequantized(t_cpu)
     base, draft = OracleLM(t_cpu, "bf16"), OracleLM(d_cpu, "bf16")
     pipe = OraclePipeline(base, draft, k=k, eos_token_id=tgt.config.eos_token_id, reprefill=True)
     # warm: materialise the fp32 weight copies outside the timed region
@@ -143,7 +150,8 @@ def main():
 
     log(f"rank {rank}/{world}: building {args.target} + {args.draft} weights on {device}")
     drf, tgt, source = build_models(args, device)
-    pipe = SpeculativePipeline(base_lm=HipLM(tgt), draft_lm=HipLM(drf), controller="fixed",
+    wd = args.weight_dtype
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt, weight_dtype=wd), draft_lm=HipLM(drf, weight_dtype=wd), controller="fixed",
                                controller_params={"k": args.k}, seed=1234)
     K, B = args.k, args.batch
     prompts = prompts_for(rank, B, tgt.config.vocab)
@@ -190,11 +198,13 @@ def main():
     value = job.tokens_per_s()
     ms_per_step = t_max / args.steps * 1e3
     bytes_step = K * drf.matmul_bytes() + tgt.matmul_bytes()
+    if wd == "fp8":
+        bytes_step //= 2      # one byte per weight (+ 4 bytes per output row of scales: < 0.1 %)
     out = {
         "metric": "accepted tokens/sec + acceptance-rate, Llama-3.2-3B/1B K=4 @1/2/4/8 GPU",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
         "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}, "
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
@@ -242,7 +252,7 @@ def main():
     # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------------------------
     if world == 1 and args.cpu_baseline_steps > 0:
         gpu_rows = [list(r.generated) for r in sess.rows]
-        cb, same = cpu_baseline(drf, tgt, prompts, K, args.cpu_baseline_steps, gpu_rows)
+        cb, same = cpu_baseline(drf, tgt, prompts, K, args.cpu_baseline_steps, gpu_rows, wd)
         out["cpu_baseline"] = cb
         out["parity_with_cpu_sample"] = same
         out["speedup_vs_cpu_baseline"] = value / cb["value"] if cb["value"] > 0 else None

@@ -187,7 +187,9 @@ typedef struct sd_model_config {
   int arch;                 /* enum sd_arch */
   int n_layers, d_model, n_heads, n_kv_heads, head_dim, d_ff, vocab, max_pos;
   float norm_eps;
-  int weight_dtype;         /* SD_BF16 */
+  int weight_dtype;         /* SD_BF16: stream the matrices as given. SD_FP8_E4M3: the matrices are still passed as
+                             * bf16; sd_pack_weights quantises them (OCP e4m3, per-output-row absmax/448 scale) into
+                             * `packed` and the forward streams that copy: half the HBM bytes, bf16 activations */
   const void* tok_emb;      /* [vocab][d] */
   const void* pos_emb;      /* [max_pos][d], GPT-2 only */
   const void* final_norm_w; /* [d] */
@@ -200,6 +202,11 @@ typedef struct sd_model_config {
                                GEMVs then stream the packed copy (the row-major matrices are no
                                longer read by the forward, except tok_emb for the gather) */
 } sd_model_config;
+
+/* The weight quantiser of the fp8 storage mode on a row-major bf16 matrix [N][K]:
+ * scales[r] = max|w[r][:]| / 448 (1 for an all-zero row), q[r][k] = OCP e4m3 (round to nearest even) of
+ * w[r][k] / scales[r]. sd_pack_weights applies exactly this before re-ordering. Asynchronous on `stream`. */
+int sd_quantize_fp8_rows(const void* w_bf16, int N, int K, void* q_fp8, float* scales, void* stream);
 
 /* Weight pre-packing: the engine's private copy of all Linear weights in the order the
  * streaming GEMV consumes them (csrc/pack.hip), so that every wave reads one contiguous

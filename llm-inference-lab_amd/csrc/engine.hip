@@ -40,8 +40,11 @@ struct sd_model {
   int* part_idx = nullptr;
   int head_grid = 0;         // grid of the last lm_head launch (partials per token)
   std::vector<const void*> packed;  // per matrix (4 per layer + lm_head) or empty: row-major weights
+  std::vector<const float*> scales; // fp8 storage: fp32 row scales per matrix
   const void* mat(int index, const void* row_major) const { return packed.empty() ? row_major : packed[index]; }
   int is_packed() const { return packed.empty() ? 0 : 1; }
+  int w8() const { return scales.empty() ? 0 : 1; }
+  const float* scale(int index) const { return scales.empty() ? nullptr : scales[index]; }
 };
 
 namespace sd {
@@ -103,11 +106,13 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     g.max_pos = c.max_pos;
     g.l_max = m->Lmax;
     g.out_dtype = SD_BF16;
+    g.w8 = m->w8();
 
     // 1. norm + QKV projection + RoPE + in-place KV append
     g.packed = m->is_packed();
     GemvArgs a1 = g;
     a1.W = m->mat(4 * l + 0, w.wqkv);
+    a1.w_scale = m->scale(4 * l + 0);
     a1.bias = w.bqkv;
     a1.N = (Hq + 2 * Hkv) * D;
     a1.K = d;
@@ -146,6 +151,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     // 3. output projection + residual
     GemvArgs a3 = g;
     a3.W = m->mat(4 * l + 1, w.wo);
+    a3.w_scale = m->scale(4 * l + 1);
     a3.bias = w.bo;
     a3.N = d;
     a3.K = Hq * D;
@@ -160,6 +166,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     // 4. norm + up projection (+ gate) + activation
     GemvArgs a4 = g;
     a4.W = m->mat(4 * l + 2, w.w_up);
+    a4.w_scale = m->scale(4 * l + 2);
     a4.bias = w.b_up;
     a4.K = d;
     a4.x = m->x;
@@ -183,6 +190,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     // 5. down projection + residual
     GemvArgs a5 = g;
     a5.W = m->mat(4 * l + 3, w.w_down);
+    a5.w_scale = m->scale(4 * l + 3);
     a5.bias = w.b_down;
     a5.N = d;
     a5.K = ff;
@@ -199,6 +207,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   // final norm + lm_head with the argmax fused into the epilogue
   GemvArgs h{};
   h.packed = m->is_packed();
+  h.w8 = m->w8();
+  h.w_scale = m->scale(4 * c.n_layers);
   h.W = m->mat(4 * c.n_layers, c.lm_head);
   h.N = c.vocab;
   h.K = d;
@@ -273,7 +283,9 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
   clear_error();
   SD_REQUIRE(cfg && out, "model_create: NULL argument");
   SD_REQUIRE(cfg->arch == SD_ARCH_LLAMA || cfg->arch == SD_ARCH_GPT2, "model_create: arch %d", cfg->arch);
-  SD_REQUIRE(cfg->weight_dtype == SD_BF16, "model_create: only bf16 weights are supported (got %d)", cfg->weight_dtype);
+  SD_REQUIRE(cfg->weight_dtype == SD_BF16 || cfg->weight_dtype == SD_FP8_E4M3,
+             "model_create: weight_dtype %d (SD_BF16, or SD_FP8_E4M3 = stream the fp8 copy made by sd_pack_weights)", cfg->weight_dtype);
+  SD_REQUIRE(cfg->weight_dtype != SD_FP8_E4M3 || cfg->packed, "model_create: fp8 storage needs the packed buffer of sd_pack_weights");
   SD_REQUIRE(cfg->n_layers > 0 && cfg->d_model > 0 && cfg->n_heads > 0 && cfg->n_kv_heads > 0 &&
                  cfg->head_dim > 0 && cfg->d_ff > 0 && cfg->vocab > 0 && cfg->max_pos > 0,
              "model_create: non-positive dimension");
@@ -309,11 +321,29 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
     int want = env ? atoi(env) : kSkinnyMaxT;
     if (want < kGemvMaxT) want = kGemvMaxT;
     if (want > kSkinnyMaxT) want = kSkinnyMaxT;
-    m->max_t = ok ? want : kGemvMaxT;
+    m->max_t = (ok && cfg->weight_dtype == SD_BF16) ? want : kGemvMaxT;  // the multi-token kernel streams bf16 only
+  }
+  if (cfg->weight_dtype == SD_FP8_E4M3) {
+    // every matrix must split into whole 64-k steps per K slice
+    const sd_model_config& c = m->cfg;
+    const bool llama = (c.arch == SD_ARCH_LLAMA);
+    const int shapes[5][2] = {{(c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model}, {c.d_model / 2, c.n_heads * c.head_dim},
+                              {llama ? c.d_ff : c.d_ff / 2, c.d_model}, {c.d_model / 2, c.d_ff}, {(c.vocab + 1) / 2, c.d_model}};
+    for (const auto& sh : shapes) {
+      const GemvGeom q = gemv_geometry(sh[0], sh[1]);
+      if (sh[1] % 64 != 0 || q.kw % 64 != 0 || q.kw * q.ksplit != sh[1]) {
+        delete m;
+        SD_REQUIRE(false, "model_create: fp8 storage does not cover a matrix with K=%d (K slice %d)", sh[1], q.kw);
+      }
+    }
   }
   if (cfg->packed) {
     const char* base = static_cast<const char*>(cfg->packed);
-    for (int i = 0; i <= 4 * cfg->n_layers; ++i) m->packed.push_back(base + packed_offset(m->cfg, i));
+    for (int i = 0; i <= 4 * cfg->n_layers; ++i) {
+      m->packed.push_back(base + packed_offset(m->cfg, i));
+      if (cfg->weight_dtype == SD_FP8_E4M3)
+        m->scales.push_back(reinterpret_cast<const float*>(base + packed_offset(m->cfg, i) + packed_scale_offset(m->cfg, i)));
+    }
   }
   *out = m;
   return 0;
@@ -396,6 +426,8 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     GemvArgs g{};
     g.debug_ts = dbg;
     g.packed = m->is_packed();
+    g.w8 = m->w8();
+    g.w_scale = m->scale(which == 4 ? 4 * c.n_layers : 4 * (l % c.n_layers) + which);
     const int li = l % c.n_layers;
     g.T = T;
     g.M = T;
@@ -434,6 +466,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     case 3: bytes = 2.0 * d * ff; break;
     default: bytes = 2.0 * c.vocab * d; break;
   }
+  if (m->w8()) bytes *= 0.5;  // one byte per weight
   for (int i = 0; i < 3; ++i)
     if (int rc = launch(i)) return rc;
   SD_HIP_CHECK(hipEventRecord(e0, st));

@@ -129,7 +129,11 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
 //   TT = compile-time bound on the token count (1, 2, 3, 5 or 9): the prologue's loads are
 //   unconditional straight-line code, which lets hipcc wait for them with a counted vmcnt
 //   while the weight batch issued after them is still in flight.
-template <int EPI, bool MASK, int TT>
+//   W8 = the weights are OCP fp8 e4m3 in the packed order of csrc/pack.hip: a lane's 16-byte load
+//   holds its A fragments of two consecutive 32-k steps; they are widened to bf16 in registers
+//   (v_cvt_scalef32_pk_bf16_fp8, exact) and feed two bf16 MFMAs; the fp32 sum of row r is scaled by
+//   w_scale[r] in the epilogue. Half the HBM bytes per token, bf16 activations unchanged.
+template <int EPI, bool MASK, int TT, bool W8>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   const int tslot = wave / ksplit;
   const int kw = a.kw;                         // K span of one slice (multiple of 32)
   const int k_begin = kpart * kw;
-  const int steps = kw >> 5;
+  const int steps = W8 ? (kw >> 6) : (kw >> 5);  // loads per slice (an fp8 load covers 64 k)
   const uint16_t* W = static_cast<const uint16_t*>(a.W);
 
   // contiguous pair range of this workgroup, cut into n_tiles tiles of tile_pairs pairs
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       if (jp >= np) { jp = 0; second = 0; }  // alias a valid lane: same address, no extra traffic
       wstride = np * 64;
       lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
+      if constexpr (W8) return W + static_cast<size_t>(p0) * ((K + 63) & ~63) + static_cast<size_t>(k_begin >> 6) * wstride;  // 1 byte per weight
       return W + static_cast<size_t>(p0) * 2 * K32 + static_cast<size_t>(k_begin >> 5) * wstride;
     }
     int p = p0 + (n & 7);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     for (int j = 0; j < kBatch; ++j) {
       const int s = s0 + j;
       bool ok = s < steps;  // wave-uniform
-      if constexpr (MASK) ok = ok && (a.packed ? (k_begin + s * 32 < K32) : (k_begin + s * 32 + g * 8 + 8 <= K));
+      if constexpr (MASK && !W8) ok = ok && (a.packed ? (k_begin + s * 32 < K32) : (k_begin + s * 32 + g * 8 + 8 <= K));
       if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + static_cast<size_t>(s) * wstride + lane_off));
       else buf[j] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -353,15 +358,31 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         for (int j = 0; j < kBatch; ++j) {
           const int s = s0 + j;
           if (s < steps) {
-            u32x4 xb;
-            if constexpr (MASK) {
-              const bool ok = (k_begin + s * 32 + g * 8 + 8 <= K);
-              xb = ok ? *reinterpret_cast<const u32x4*>(xrow + s * 32) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (W8) {
+              // 16 fp8 -> two bf16x8 fragments (k = 64 s + 8 g + 0..7 and + 32)
+              u32x4 lo, hi;
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                lo[2 * e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][e], 1.0f, false));
+                lo[2 * e + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][e], 1.0f, true));
+                hi[2 * e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][2 + e], 1.0f, false));
+                hi[2 * e + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][2 + e], 1.0f, true));
+              }
+              const u32x4 xb0 = *reinterpret_cast<const u32x4*>(xrow + s * 64);
+              const u32x4 xb1 = *reinterpret_cast<const u32x4*>(xrow + s * 64 + 32);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, lo), __builtin_bit_cast(bf16x8_t, xb0), acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hi), __builtin_bit_cast(bf16x8_t, xb1), acc, 0, 0, 0);
             } else {
-              xb = *reinterpret_cast<const u32x4*>(xrow + s * 32);
+              u32x4 xb;
+              if constexpr (MASK) {
+                const bool ok = (k_begin + s * 32 + g * 8 + 8 <= K);
+                xb = ok ? *reinterpret_cast<const u32x4*>(xrow + s * 32) : u32x4{0u, 0u, 0u, 0u};
+              } else {
+                xb = *reinterpret_cast<const u32x4*>(xrow + s * 32);
+              }
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
+                                                            __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
             }
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
-                                                          __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
           }
         }
       }
@@ -388,6 +409,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         }
         int r0, r1;
         pair_rows<EPI>(a, p, r0, r1);
+        if constexpr (W8) {
+          y0 *= a.w_scale[r0];
+          y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;
+        }
         epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i, have_old && r == 0 && it == tid, old_pre);
       }
     }
@@ -434,28 +459,33 @@ int gemv_grid(const GemvArgs& a, int* ppw_out) {
   return q.grid;
 }
 
-template <int EPI, bool MASK, int TT>
+template <int EPI, bool MASK, int TT, bool W8>
 static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into once per kernel
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT>),
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT, W8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8>), dim3(grid), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
+template <int EPI, bool W8>
+static int launch_epi_w(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
+  if (mask) return launch_one<EPI, true, kGemvMaxT, W8>(a, grid, smem, st);  // generic shapes: one variant
+  if (a.T <= 1) return launch_one<EPI, false, 1, W8>(a, grid, smem, st);
+  if (a.T <= 2) return launch_one<EPI, false, 2, W8>(a, grid, smem, st);
+  if (a.T <= 3) return launch_one<EPI, false, 3, W8>(a, grid, smem, st);
+  if (a.T <= 5) return launch_one<EPI, false, 5, W8>(a, grid, smem, st);
+  return launch_one<EPI, false, kGemvMaxT, W8>(a, grid, smem, st);
+}
+
 template <int EPI>
 static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
-  if (mask) return launch_one<EPI, true, kGemvMaxT>(a, grid, smem, st);  // generic shapes: one variant
-  if (a.T <= 1) return launch_one<EPI, false, 1>(a, grid, smem, st);
-  if (a.T <= 2) return launch_one<EPI, false, 2>(a, grid, smem, st);
-  if (a.T <= 3) return launch_one<EPI, false, 3>(a, grid, smem, st);
-  if (a.T <= 5) return launch_one<EPI, false, 5>(a, grid, smem, st);
-  return launch_one<EPI, false, kGemvMaxT>(a, grid, smem, st);
+  return a.w8 ? launch_epi_w<EPI, true>(a, mask, grid, smem, st) : launch_epi_w<EPI, false>(a, mask, grid, smem, st);
 }
 
 int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
@@ -475,6 +505,10 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
   // MASK variant: slices that are not whole 32-k steps, or rows longer than the one-chunk-per-
   // thread register staging covers
   const bool mask = (a.kw * ksplit != a.K) || (a.K / 8 > kGemvThreads);
+  if (a.w8) {
+    SD_REQUIRE(a.packed && a.w_scale, "gemv: fp8 weights need the packed layout and row scales");
+    SD_REQUIRE(a.K % 64 == 0 && a.kw % 64 == 0 && a.kw * ksplit == a.K, "gemv: fp8 weights need K (%d) and the K slice (%d) in whole 64-k steps", a.K, a.kw);
+  }
   size_t smem = gemv_smem(a.T, a.K, false);
   a.alias_part = 0;
   if (smem > kLdsLimit && n_tiles <= kGemvWaves / ksplit) {  // single round: partials may alias x

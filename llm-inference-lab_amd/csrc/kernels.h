@@ -27,6 +27,8 @@ struct GemvArgs {
   int alias_part;    // partial sums alias the staged x rows (set by launch_gemv)
   unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
   int packed;                    // W is in the packed tile-stream order of csrc/pack.hip
+  int w8;                        // W holds OCP fp8 e4m3 values (packed only); acc of row r is scaled by w_scale[r]
+  const float* w_scale;          // fp32 [N] row scales (w8)
   // activations in: bf16 [T][x_stride]
   const void* x;
   int x_stride;
@@ -63,6 +65,7 @@ struct GemvGeom {
 };
 GemvGeom gemv_geometry(int n_pairs, int K);
 size_t packed_matrix_bytes(int n_pairs, int K);
+size_t packed_scale_offset(const sd_model_config& c, int index);  // fp8: row scales follow the packed bytes of a matrix
 size_t packed_offset(const sd_model_config& c, int index);  // index: 4*layer + {0 qkv,1 out,2 up,3 down}; 4*n_layers = lm_head
 int gemv_grid(const GemvArgs& a, int* ppw_out);
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip

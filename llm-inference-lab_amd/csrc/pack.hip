@@ -10,6 +10,14 @@
 // stream: each wave walks one contiguous region of HBM. Rows of a tile are its pairs' first
 // rows, then their second rows (pair_rows). K is padded to a multiple of 32 with zeros, a
 // missing second row (odd vocabulary) is a zero row. The packed size is n_pairs*2*K32*2 bytes.
+//
+// fp8 storage (sd_model_config.weight_dtype = SD_FP8_E4M3): the same blocks, but a lane's 16
+// bytes are 16 OCP e4m3 values — its fragments of TWO consecutive 32-k steps (k = 64 S + 8 g + 0..7
+// and k = 64 S + 32 + 8 g + 0..7) — so one load feeds two MFMAs and the stream is half as long.
+// Quantisation happens here, on the device, from the bf16 matrices the caller passes:
+// per output row r, scale[r] = max|w[r][:]| / 448 (1 for an all-zero row), q = rne_e4m3(w / scale[r]);
+// the kernel multiplies the fp32 accumulator of row r by scale[r]. The scales (fp32 [N]) follow the
+// packed bytes of their matrix. K is padded to a multiple of 64.
 
 #include "kernels.h"
 
@@ -80,6 +88,78 @@ __global__ __launch_bounds__(256) void pack_kernel(PackJob j) {
   }
 }
 
+// scale[r] = max |w[r][:]| / 448, one wave per row
+__global__ __launch_bounds__(kWave) void row_scale_kernel(const uint16_t* __restrict__ w, int N, int K, float* __restrict__ scale) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float m = 0.f;
+  for (int k = lane; k < K; k += kWave) m = fmaxf(m, fabsf(bf16_bits_to_float(w[static_cast<size_t>(r) * K + k])));
+  m = wave_reduce_max(m);
+  if (lane == 0) scale[r] = m > 0.f ? m / 448.0f : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void pack_fp8_kernel(PackJob j, const float* __restrict__ scale) {
+  const int K64 = (j.K + 63) & ~63;
+  const int qn = K64 >> 4;  // 16-byte chunks (16 fp8) per packed row
+  const size_t total = static_cast<size_t>(j.n_pairs) * 2 * qn;
+  uint8_t* dst = reinterpret_cast<uint8_t*>(j.dst);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * 256) {
+    const int q = static_cast<int>(i % qn);
+    const size_t t = i / qn;
+    const int second = static_cast<int>(t & 1);
+    const int p = static_cast<int>(t >> 1);
+    const int c = p / j.ppw;
+    const int p_lo = c * j.ppw;
+    const int p_hi = min(p_lo + j.ppw, j.n_pairs);
+    const int tile = (p - p_lo) / j.tile_pairs;
+    const int p0 = p_lo + tile * j.tile_pairs;
+    const int np = min(j.tile_pairs, p_hi - p0);
+    const int jp = p - p0;
+    const int S = q >> 2, g = q & 3;  // double step (64 k), k-group
+    const size_t dst_chunk = static_cast<size_t>(p0) * 2 * qn + static_cast<size_t>(S) * (2 * np * 4) + g * 2 * np + second * np + jp;
+    int r0, r1;
+    pack_pair_rows(j, p, r0, r1);
+    const int r = second ? r1 : r0;
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+    if (r < j.N) {
+      const float sc = scale[r];
+      const uint16_t* row = j.src + static_cast<size_t>(r) * j.K;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int k0 = 64 * S + 32 * half + 8 * g;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (k0 + e < j.K) ? bf16_bits_to_float(row[k0 + e]) / sc : 0.f;
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        out[2 * half] = static_cast<uint32_t>(lo);
+        out[2 * half + 1] = static_cast<uint32_t>(hi);
+      }
+    }
+    *reinterpret_cast<uint4*>(dst + dst_chunk * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// row-major fp8 image of a matrix with the scales of row_scale_kernel (sd_quantize_fp8_rows): the same
+// arithmetic as pack_fp8_kernel, kept separately so that the quantiser can be checked bit for bit
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const uint16_t* __restrict__ w, int N, int K,
+                                                            const float* __restrict__ scale, uint8_t* __restrict__ q) {
+  const size_t total = static_cast<size_t>(N) * (K >> 2);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+    const size_t r = i / (K >> 2);
+    const int k0 = static_cast<int>(i % (K >> 2)) * 4;
+    const float sc = scale[r];
+    const uint16_t* row = w + r * K + k0;
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_bits_to_float(row[0]) / sc, bf16_bits_to_float(row[1]) / sc, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_bits_to_float(row[2]) / sc, bf16_bits_to_float(row[3]) / sc, v, true);
+    *reinterpret_cast<int*>(q + r * K + k0) = v;
+  }
+}
+
 // matrices of the model in packing order: per layer qkv, out, up, down; then lm_head
 struct MatDesc {
   const void* w;
@@ -105,13 +185,32 @@ size_t packed_matrix_bytes(int n_pairs, int K) {
   return (static_cast<size_t>(n_pairs) * 2 * K32 * 2 + 255) & ~static_cast<size_t>(255);
 }
 
+// fp8: packed bytes, then the fp32 row scales
+size_t packed_fp8_weight_bytes(int n_pairs, int K) {
+  const size_t K64 = (static_cast<size_t>(K) + 63) & ~static_cast<size_t>(63);
+  return (static_cast<size_t>(n_pairs) * 2 * K64 + 255) & ~static_cast<size_t>(255);
+}
+static size_t packed_fp8_matrix_bytes(int n_pairs, int K) {
+  return packed_fp8_weight_bytes(n_pairs, K) + ((static_cast<size_t>(n_pairs) * 2 * 4 + 255) & ~static_cast<size_t>(255));
+}
+static size_t matrix_bytes(const sd_model_config& c, const MatDesc& m) {
+  return c.weight_dtype == SD_FP8_E4M3 ? packed_fp8_matrix_bytes(m.n_pairs, m.K) : packed_matrix_bytes(m.n_pairs, m.K);
+}
+
 // byte offset of matrix `index` (same order as model_matrices) inside the packed buffer
 size_t packed_offset(const sd_model_config& c, int index) {
   std::vector<MatDesc> mats;
   model_matrices(c, mats);
   size_t off = 0;
-  for (int i = 0; i < index && i < static_cast<int>(mats.size()); ++i) off += packed_matrix_bytes(mats[i].n_pairs, mats[i].K);
+  for (int i = 0; i < index && i < static_cast<int>(mats.size()); ++i) off += matrix_bytes(c, mats[i]);
   return off;
+}
+
+// offset of the fp32 row scales of matrix `index` from the start of its packed bytes
+size_t packed_scale_offset(const sd_model_config& c, int index) {
+  std::vector<MatDesc> mats;
+  model_matrices(c, mats);
+  return packed_fp8_weight_bytes(mats[index].n_pairs, mats[index].K);
 }
 
 }  // namespace sd
@@ -123,14 +222,15 @@ extern "C" size_t sd_packed_bytes(const sd_model_config* cfg) {
   std::vector<MatDesc> mats;
   model_matrices(*cfg, mats);
   size_t n = 0;
-  for (const MatDesc& m : mats) n += packed_matrix_bytes(m.n_pairs, m.K);
+  for (const MatDesc& m : mats) n += matrix_bytes(*cfg, m);
   return n;
 }
 
 extern "C" int sd_pack_weights(const sd_model_config* cfg, void* dst, size_t dst_bytes, void* stream) {
   clear_error();
   SD_REQUIRE(cfg && cfg->layers && dst, "pack_weights: NULL argument");
-  SD_REQUIRE(cfg->weight_dtype == SD_BF16, "pack_weights: only bf16 weights");
+  SD_REQUIRE(cfg->weight_dtype == SD_BF16 || cfg->weight_dtype == SD_FP8_E4M3, "pack_weights: weight_dtype %d (bf16 or fp8 e4m3)", cfg->weight_dtype);
+  const bool fp8 = cfg->weight_dtype == SD_FP8_E4M3;
   SD_REQUIRE(dst_bytes >= sd_packed_bytes(cfg), "pack_weights: destination too small");
   SD_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 255) == 0, "pack_weights: destination must be 256-byte aligned");
   std::vector<MatDesc> mats;
@@ -143,9 +243,29 @@ extern "C" int sd_pack_weights(const sd_model_config* cfg, void* dst, size_t dst
     const GemvGeom q = gemv_geometry(m.n_pairs, m.K);
     PackJob j{static_cast<const uint16_t*>(m.w), reinterpret_cast<uint16_t*>(p), m.N, m.K, m.n_pairs, m.epi,
               cfg->head_dim, q.ppw, q.tile_pairs};
-    hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, st, j);
+    if (fp8) {
+      float* scale = reinterpret_cast<float*>(p + packed_fp8_weight_bytes(m.n_pairs, m.K));
+      hipLaunchKernelGGL(row_scale_kernel, dim3(m.N), dim3(kWave), 0, st, static_cast<const uint16_t*>(m.w), m.N, m.K, scale);
+      SD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pack_fp8_kernel, dim3(2048), dim3(256), 0, st, j, scale);
+    } else {
+      hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, st, j);
+    }
     SD_LAUNCH_CHECK();
-    p += packed_matrix_bytes(m.n_pairs, m.K);
+    p += matrix_bytes(*cfg, m);
   }
+  return 0;
+}
+
+extern "C" int sd_quantize_fp8_rows(const void* w_bf16, int N, int K, void* q_fp8, float* scales, void* stream) {
+  clear_error();
+  SD_REQUIRE(w_bf16 && q_fp8 && scales, "quantize_fp8_rows: NULL argument");
+  SD_REQUIRE(N >= 1 && K >= 4 && K % 4 == 0, "quantize_fp8_rows: N=%d K=%d (K must be a multiple of 4)", N, K);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(row_scale_kernel, dim3(N), dim3(kWave), 0, st, static_cast<const uint16_t*>(w_bf16), N, K, scales);
+  SD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3(1024), dim3(256), 0, st, static_cast<const uint16_t*>(w_bf16), N, K, scales,
+                     static_cast<uint8_t*>(q_fp8));
+  SD_LAUNCH_CHECK();
   return 0;
 }

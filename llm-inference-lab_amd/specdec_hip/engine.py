@@ -52,7 +52,13 @@ def _stream(stream: Optional[torch.cuda.Stream], device) -> int:
 class HipModel:
     """A decoder (Llama or GPT-2 shaped) bound to its KV cache on one GPU."""
 
-    def __init__(self, weights: ModelWeights, batch: int, l_max: int, device: Optional[torch.device] = None):
+    def __init__(self, weights: ModelWeights, batch: int, l_max: int, device: Optional[torch.device] = None,
+                 weight_dtype: str = "bf16"):
+        """weight_dtype "fp8": the engine streams an OCP e4m3 copy of the Linear weights (per-output-row
+        scales, quantised on the device at load); activations and the KV cache stay bf16."""
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"weight_dtype={weight_dtype!r} (bf16 or fp8)")
+        self.weight_dtype = weight_dtype
         self.lib = _abi.load()
         self.cfg: ModelConfig = weights.config
         dev = torch.device(device) if device is not None else weights.tok_emb.device
@@ -76,21 +82,23 @@ class HipModel:
         mc = _ModelConfig(
             arch=c.arch, n_layers=c.n_layers, d_model=c.d_model, n_heads=c.n_heads, n_kv_heads=c.n_kv_heads,
             head_dim=c.head_dim, d_ff=c.d_ff, vocab=c.vocab, max_pos=c.max_pos, norm_eps=c.norm_eps,
-            weight_dtype=_abi.SD_BF16, tok_emb=_ptr(weights.tok_emb), pos_emb=_ptr(weights.pos_emb),
+            weight_dtype=_abi.SD_FP8_E4M3 if weight_dtype == "fp8" else _abi.SD_BF16,
+            tok_emb=_ptr(weights.tok_emb), pos_emb=_ptr(weights.pos_emb),
             final_norm_w=_ptr(weights.final_norm_w), final_norm_b=_ptr(weights.final_norm_b),
             lm_head=_ptr(weights.lm_head), rope_cos=_ptr(weights.rope_cos), rope_sin=_ptr(weights.rope_sin),
             layers=self._layers,
         )
         # the engine's packed copy of the Linear weights (one per ModelWeights, shared by every
         # engine instance built over it)
-        packed = weights.meta.get("_packed")
-        if packed is None and not os.environ.get("SPECDEC_NO_PACK"):
+        key = "_packed" if weight_dtype == "bf16" else "_packed_fp8"
+        packed = weights.meta.get(key)
+        if packed is None and (weight_dtype == "fp8" or not os.environ.get("SPECDEC_NO_PACK")):
             nbytes = self.lib.sd_packed_bytes(ctypes.byref(mc))
             with torch.cuda.device(dev):
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 _abi.check(self.lib.sd_pack_weights(ctypes.byref(mc), packed.data_ptr(), nbytes,
                                                     torch.cuda.current_stream(dev).cuda_stream), "sd_pack_weights")
-            weights.meta["_packed"] = packed
+            weights.meta[key] = packed
         self._packed = packed
         mc.packed = _ptr(packed)
         handle = _vp()

@@ -331,3 +331,19 @@ def sample_token_hip(logits: torch.Tensor, temperature: float, top_k: Optional[i
                                        ptr(draw_counters), int(draw) & 0xFFFFFFFF, ptr(stream_ids), out.data_ptr(),
                                        _stream_ptr(dev)), "sd_sample_token")
     return out
+
+
+def quantize_fp8_rows_hip(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(q float8_e4m3fn [N][K], scales float32 [N]) of a bf16 matrix: the per-output-row quantiser of the
+    engine's fp8 weight storage (sd_quantize_fp8_rows)."""
+    lib = _abi.load()
+    dev = _require_device("quantize_fp8_rows", w)
+    if w.dtype != torch.bfloat16 or w.dim() != 2:
+        raise TypeError(f"quantize_fp8_rows: need a bf16 matrix, got {w.dtype} {tuple(w.shape)}")
+    w = w.contiguous()
+    N, K = w.shape
+    q = torch.empty((N, K), dtype=torch.uint8, device=dev)
+    sc = torch.empty(N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _abi.check(lib.sd_quantize_fp8_rows(w.data_ptr(), N, K, q.data_ptr(), sc.data_ptr(), _stream_ptr(dev)), "sd_quantize_fp8_rows")
+    return q.view(torch.float8_e4m3fn), sc

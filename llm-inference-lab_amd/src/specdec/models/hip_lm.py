@@ -54,7 +54,7 @@ class IdTokenizer:
 
 class HipLM(LanguageModel):
     def __init__(self, weights: W.ModelWeights, tokenizer: Any = None, name: Optional[str] = None,
-                 max_len: int = 1024, batch: int = 1, device: str = "cuda"):
+                 max_len: int = 1024, batch: int = 1, device: str = "cuda", weight_dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("HipLM needs a GPU: this build has no CPU compute path")
         self._device = torch.device(device if device != "auto" else "cuda")
@@ -63,6 +63,7 @@ class HipLM(LanguageModel):
         self.vocab_size = self.config.vocab
         self._tokenizer = tokenizer or IdTokenizer(self.config.vocab, self.config.eos_token_id)
         self._name = name or self.config.name
+        self.weight_dtype = weight_dtype   # "fp8": the engines stream an e4m3 copy of the Linear weights
         self._max_len, self._batch = max_len, batch
         self._model: Optional[HipModel] = None
         self._cached: List[List[int]] = []
@@ -71,7 +72,7 @@ class HipLM(LanguageModel):
     # ---- engine instances ----------------------------------------------------------
     def new_engine(self, batch: int, l_max: int) -> HipModel:
         """A forward instance with its own KV cache over the shared weights."""
-        return HipModel(self.weights, batch=batch, l_max=l_max, device=self._device)
+        return HipModel(self.weights, batch=batch, l_max=l_max, device=self._device, weight_dtype=self.weight_dtype)
 
     def _engine(self, batch: int, need_len: int) -> HipModel:
         m = self._model

@@ -148,3 +148,24 @@ def test_config1_gpt2_distilgpt2_shapes_k2():
     gb, wb = pipe.generate_batch([prompt], max_tokens=12, do_sample=False)[0], oracle.generate_batch([prompt], 12)[0]
     assert gb["generated_tokens"] == wb["generated_tokens"]
     assert (gb["proposed"], gb["accepted"]) == (wb["proposed"], wb["accepted"])
+
+
+def test_run_specdec_cli_prints_the_reference_json(capsys, monkeypatch):
+    """CLI counterpart (reference run_specdec.py): one JSON line with the reference's keys."""
+    import json as _json
+
+    from src.specdec import run_specdec
+    from src.specdec.models import hip_lm
+
+    drf, tgt = tiny_pair()
+    made = {"synthetic:tiny-target": tgt, "synthetic:tiny-draft": drf}
+    real = hip_lm.create_hip_lm
+    monkeypatch.setattr("src.specdec.core.pipeline.create_hip_lm", lambda spec, **kw: real(made[spec].to("cuda"), **kw))
+    rc = run_specdec.main(["--prompt", "5 6 7 8", "--max-tokens", "12", "--K", "2", "--base-model", "synthetic:tiny-target",
+                           "--draft-model", "synthetic:tiny-draft"])
+    assert rc == 0
+    out = _json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert set(out) == {"latency_ms", "proposed", "accepted", "acceptance_rate", "tokens_per_sec", "text", "impl", "device",
+                        "base_model", "draft_model", "draft_mode", "dtype"}
+    assert out["impl"] == "hip" and out["proposed"] > 0 and len(out["text"].split()) == 12
+    assert run_specdec.main(["--prompt", "5 6", "--K", "2", "--adaptive-K"]) == 1
