@@ -232,7 +232,7 @@ def main():
         # runs, FETCH_SIZE x2 on gfx950): counters cannot be read from inside this process, so the
         # figure comes from the committed summary of the same command (profiles/summarize.py)
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-        if os.path.exists(pmc) and B * (K + 1) == 5:
+        if os.path.exists(pmc) and B * (K + 1) == 5 and wd == "bf16" and args.target == "llama-3.2-3b":
             with open(pmc) as f:
                 t = json.load(f).get("gemv_mfma_kernel<2, false, 5>")
             if t:

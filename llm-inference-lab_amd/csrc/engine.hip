@@ -36,6 +36,7 @@ struct sd_model {
   uint16_t* attn = nullptr;  // [64][Hq*D]
   uint16_t* act = nullptr;   // [64][ff]
   float* part_val = nullptr; // [64][512]
+  int small_t = sd::kGemvMaxT; // tokens per pass of gemv.hip for this model's widest activation row (<= 9)
   int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
   int* part_idx = nullptr;
   int head_grid = 0;         // grid of the last lm_head launch (partials per token)
@@ -249,7 +250,7 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
   const int esz = (logits_dtype == SD_F32) ? 4 : 2;
   SD_REQUIRE(!logits_out || logits_dtype == SD_F32 || logits_dtype == SD_BF16, "forward: logits dtype %d", logits_dtype);
   const int V = m->cfg.vocab;
-  const int cap = (B * M <= kGemvMaxT) ? kGemvMaxT : m->max_t;  // tokens per pass
+  const int cap = (B * M <= m->small_t) ? m->small_t : m->max_t;  // tokens per pass
   if (M <= cap) {
     const int Bc = cap / M;
     for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -319,9 +320,12 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
                     gemm_skinny_covers(kSkinnyMaxT, (c.vocab + 1) / 2, c.d_model);
     const char* env = getenv("SPECDEC_MAX_PASS_TOKENS");  // testing knob: 9 forces the small-T kernel everywhere
     int want = env ? atoi(env) : kSkinnyMaxT;
-    if (want < kGemvMaxT) want = kGemvMaxT;
     if (want > kSkinnyMaxT) want = kSkinnyMaxT;
-    m->max_t = (ok && cfg->weight_dtype == SD_BF16) ? want : kGemvMaxT;  // the multi-token kernel streams bf16 only
+    int kmax = c.d_model > HqD ? c.d_model : HqD;
+    if (c.d_ff > kmax) kmax = c.d_ff;
+    m->small_t = gemv_max_tokens(kmax);  // e.g. 5 for d_ff = 14336: x rows must fit the CU's LDS
+    if (want < m->small_t) want = m->small_t;
+    m->max_t = (ok && cfg->weight_dtype == SD_BF16) ? want : m->small_t;  // the multi-token kernel streams bf16 only
   }
   if (cfg->weight_dtype == SD_FP8_E4M3) {
     // every matrix must split into whole 64-k steps per K slice

@@ -453,6 +453,13 @@ static size_t gemv_smem(int T, int K, bool alias) {
   return (alias ? (xs > part ? xs : part) : xs + part) + red;
 }
 
+// most tokens one launch can stage for rows of K elements (x rows + aliased partials in 160 KiB)
+int gemv_max_tokens(int K) {
+  int t = kGemvMaxT;
+  while (t > 1 && gemv_smem(t, K, true) > kLdsLimit) --t;
+  return t;
+}
+
 int gemv_grid(const GemvArgs& a, int* ppw_out) {
   const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
   *ppw_out = q.ppw;

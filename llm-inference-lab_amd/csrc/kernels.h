@@ -68,6 +68,7 @@ size_t packed_matrix_bytes(int n_pairs, int K);
 size_t packed_scale_offset(const sd_model_config& c, int index);  // fp8: row scales follow the packed bytes of a matrix
 size_t packed_offset(const sd_model_config& c, int index);  // index: 4*layer + {0 qkv,1 out,2 up,3 down}; 4*n_layers = lm_head
 int gemv_grid(const GemvArgs& a, int* ppw_out);
+int gemv_max_tokens(int K);                                          // tokens gemv.hip can stage for rows of K elements (<= 9)
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip
 int launch_gemm_skinny(const GemvArgs& a, int epi, hipStream_t st);   // T <= 64
 bool gemm_skinny_covers(int T, int n_pairs, int K);                  // shape handled by gemm_skinny.hip
