@@ -136,14 +136,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback to time)")
+    # SPECDEC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: every rank
+    # shares cuda:0 and the one collective runs over gloo on host tensors (the real job is RCCL)
+    rehearsal = os.environ.get("SPECDEC_BENCH_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    stats_device = torch.device("cpu") if rehearsal else device
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     from src.specdec import HipLM, SpeculativePipeline
     from specdec_hip.engine import HipSpecDec
@@ -187,7 +196,7 @@ def main():
 
     # the one collective of the job: a 48-byte struct per rank, all-gathered over RCCL/xGMI
     job = gather_stats({"tokens": n_tok, "proposed": proposed, "accepted": accepted_ref,
-                        "accepted_strict": accepted_strict, "wall_ns": int(dt_local * 1e9), "steps": args.steps}, device)
+                        "accepted_strict": accepted_strict, "wall_ns": int(dt_local * 1e9), "steps": args.steps}, stats_device)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -16,6 +16,8 @@
 // batch. The reference has no such kernel: its verify is K sequential HF forwards per row
 // (speculative_scheduler.py:192-199) and its prefill is HF's.
 
+#include <stdlib.h>
+
 #include "gemv_device.h"
 
 namespace sd {
@@ -292,6 +294,146 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
   }
 }
 
+// ------------------------------------------------------------------------------
+// Direct-operand variant for matrices WITHOUT a fused normalisation whose workgroup share is a single
+// round of tiles (out-projection and down-projection: N = d_model, <= 8 pairs per workgroup,
+// ksplit = 16): there a staged x chunk is read by exactly one wave per K slice, so LDS staging buys
+// no reuse and its two workgroup barriers per chunk are pure cost (26 us for the 3B down-projection
+// at 40 tokens). Here every wave loads its B fragments (16 tokens x 32 k, 16 bytes per lane, L2
+// resident) straight into registers next to the A fragments, batch by batch, and runs free of the
+// other waves until the K-slice reduction — the structure of gemv.hip with TG token groups.
+// ------------------------------------------------------------------------------
+template <int EPI, int TG>
+__global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NB = (TG == 1) ? 10 : (TG == 2) ? 6 : (TG == 3) ? 5 : 4;   // steps per batch: NB * (1 + TG) 16-byte loads in flight per lane
+  const int K = a.K, T = a.T;
+  float* part = reinterpret_cast<float*>(smem);  // [16 waves][TG][16][16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int ksplit = a.ksplit;
+  const int tiles_per_round = kGemvWaves / ksplit;
+  const int kpart = wave & (ksplit - 1);
+  const int tslot = wave / ksplit;
+  const int k_begin = kpart * a.kw;
+  const int steps = a.kw >> 5;
+  const uint16_t* W = static_cast<const uint16_t*>(a.W);
+  const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
+  const int p_hi = min(p_lo + a.ppw, a.n_pairs);
+  const int tile_pairs = a.tile_pairs;
+  const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;   // <= tiles_per_round (launcher)
+
+  // A fragment address: base + step * wstride + lane_off (as gemv.hip)
+  int wstride = 32;
+  unsigned lane_off = 0;
+  const uint16_t* wbase;
+  {
+    const int tile = tslot < n_tiles ? tslot : 0;
+    const int p0 = p_lo + tile * tile_pairs;
+    if (a.packed) {
+      int np = min(tile_pairs, p_hi - p0);
+      if (np < 1) np = 1;
+      int jp = n & 7, second = n >> 3;
+      if (jp >= np) { jp = 0; second = 0; }
+      wstride = np * 64;
+      lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
+      wbase = W + static_cast<size_t>(p0) * 2 * K + static_cast<size_t>(k_begin >> 5) * wstride;
+    } else {
+      int p = p0 + (n & 7);
+      int second = n >> 3;
+      if ((n & 7) >= tile_pairs || p >= p_hi) { p = min(p0, p_hi - 1); second = 0; }
+      int r0, r1;
+      pair_rows<EPI>(a, p, r0, r1);
+      int r = second ? r1 : r0;
+      if (r >= a.N) r = r0;
+      lane_off = static_cast<unsigned>(r) * static_cast<unsigned>(K) + static_cast<unsigned>(g * 8);
+      wbase = W + k_begin;
+    }
+  }
+  // B fragment rows of this lane: token 16 q + n (columns >= T read row T-1; never used)
+  const uint16_t* xin = static_cast<const uint16_t*>(a.x);
+  const uint16_t* xrow[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    const int t = 16 * q + n;
+    xrow[q] = xin + static_cast<size_t>(t < T ? t : T - 1) * a.x_stride + k_begin + g * 8;
+  }
+
+  f32x4_t acc[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (tslot < n_tiles) {
+    for (int s0 = 0; s0 < steps; s0 += NB) {
+      u32x4 wb[NB], xb[NB][TG];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int s = s0 + j;
+        if (s < steps) {  // wave-uniform
+#pragma unroll
+          for (int q = 0; q < TG; ++q) xb[j][q] = *reinterpret_cast<const u32x4*>(xrow[q] + s * 32);
+          wb[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + static_cast<size_t>(s) * wstride + lane_off));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (s0 + j < steps) {
+#pragma unroll
+          for (int q = 0; q < TG; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[j]), __builtin_bit_cast(bf16x8_t, xb[j][q]),
+                                                             acc[q], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* slot = part + static_cast<size_t>(wave) * TG * 256;
+#pragma unroll
+  for (int q = 0; q < TG; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slot[q * 256 + (4 * g + e) * 16 + n] = acc[q][e];
+  __syncthreads();
+  float best_v[TG];
+  int best_i[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) { best_v[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+  for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
+    const int tsl = it >> 7, jp = (it >> 4) & 7, tl = it & 15;
+    const int p = p_lo + tsl * tile_pairs + jp;
+    if (tsl < n_tiles && jp < tile_pairs && p < p_hi) {
+      int r0, r1;
+      pair_rows<EPI>(a, p, r0, r1);
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int t = 16 * q + tl;
+        if (t < T) {
+          const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
+          float y0 = 0.f, y1 = 0.f;
+          for (int w = 0; w < ksplit; ++w) {
+            y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
+            y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
+          }
+          epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
+  const int TG = (a.T + 15) / 16;
+  const size_t smem = skinny_part_bytes(TG);   // <= 64 KiB
+  switch (TG) {
+    case 1: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 1>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
+    case 2: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 2>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
+    case 3: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 3>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
+    default: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 4>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
+  }
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int EPI, int TG>
 static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
   static bool attr_set = false;
@@ -339,6 +481,10 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   sg.sc_shift = 0;
   while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
   const int TG = (a.T + 15) / 16;
+  // un-normalised, single-round shapes (out / down projections): operands straight to registers
+  if (a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
+    if (epi == EPI_RESID) return launch_direct<EPI_RESID>(a, q.grid, st);
+  }
   const size_t smem = skinny_smem(a.T, TG, sg.kc);
   switch (epi) {
     case EPI_QKV_ROPE: return launch_skinny_epi<EPI_QKV_ROPE>(a, sg, q.grid, smem, st);
