@@ -188,6 +188,7 @@ def main():
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     barrier()
+    sess.finish()
     n_tok = sum(len(r.generated) for r in sess.rows) - n0
     proposed = sess.stats["proposed"] - p0
     accepted_ref = sum(r.accepted for r in sess.rows) - a0          # reference definition (bonus counted)

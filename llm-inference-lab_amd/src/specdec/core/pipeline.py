@@ -66,11 +66,11 @@ def _clamp(tok: int, vocab: int) -> int:
 
 
 class _Row:
-    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws")
+    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws", "steps")
 
     def __init__(self, seq: List[int]):
         self.seq, self.generated, self.active = seq, [], True
-        self.proposed = self.accepted = self.draws = 0
+        self.proposed = self.accepted = self.draws = self.steps = 0
 
 
 class SpeculativePipeline:
@@ -253,18 +253,19 @@ class SpeculativePipeline:
 
     # ------------------------------------------------------------------ the loop
     def start_session(self, prompts: List[List[int]], max_tokens: int, emit_mode: int,
-                      sampling: Optional[Dict[str, Any]] = None) -> "DecodeSession":
+                      sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None) -> "DecodeSession":
         """Prefill + device state for a batch of rows; `advance()` then runs one step at a time
         (generate / generate_batch drive it to completion, bench.py times exact step counts)."""
-        return DecodeSession(self, prompts, max_tokens, emit_mode, sampling)
+        return DecodeSession(self, prompts, max_tokens, emit_mode, sampling, step_limit)
 
     def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int,
                 sampling: Optional[Dict[str, Any]] = None):
         t_start = time.time()
-        sess = self.start_session(prompts, max_tokens, emit_mode, sampling)
-        while sess.step < step_limit and sess.any_active():
+        sess = self.start_session(prompts, max_tokens, emit_mode, sampling, step_limit)
+        while sess.any_active():    # every row stops after `step_limit` steps of its own
             if not sess.advance():
                 break
+        sess.finish()
         torch.cuda.synchronize()
         st = sess.stats
         st["total_ms"] = (time.time() - t_start) * 1e3
@@ -373,12 +374,23 @@ class SpeculativePipeline:
 
 
 class DecodeSession:
-    """One batch of rows being decoded: host mirror of the sequences + the device loop."""
+    """One batch of rows being decoded: host mirror of the sequences + the device loop.
+
+    The device advances its own state at the end of a step, so the NEXT step does not need anything
+    from the host. With a fixed K and greedy decoding `advance()` therefore launches step s+1 as soon as
+    the record of step s has arrived and applies the reference's host rules to that record while the GPU
+    is already running: the host's turn (rules, bookkeeping, most of the graph-launch call) leaves the
+    critical path. When the rules change a row (it finishes, or a de-duplication rewrites it), the step
+    already in flight is void FOR THAT ROW: its record is ignored, the row's device state is repaired at
+    the next launch point (the stream is idle there), and it rejoins one step later. Steps are counted
+    per row, so the reference's step bound applies to each row's own valid steps. Adaptive K and the
+    sampled mode keep the launch -> wait -> rules order (the next launch depends on the host there)."""
 
     def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int,
-                 sampling: Optional[Dict[str, Any]] = None):
+                 sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None):
         self.pipe, self.max_tokens, self.emit_mode = pipe, max_tokens, emit_mode
         self.sampling = sampling
+        self.step_limit = step_limit
         if sampling is not None and emit_mode != HipSpecDec.EMIT_BONUS:
             raise ValueError("sampling is a generate_batch (bonus-token) feature")
         self.rows = [_Row(list(p)) for p in prompts]
@@ -396,8 +408,15 @@ class DecodeSession:
         for b, r in enumerate(self.rows):
             pipe._set_row(self.loop, b, r)
         self._apply_sampling()
-        self.stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0}
+        self.stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
         self.step = 0
+        from ..policies.controllers import FixedKController
+
+        self._early = (isinstance(ctl, FixedKController) and sampling is None
+                       and os.environ.get("SPECDEC_EARLY_LAUNCH", "1") != "0")
+        self._inflight = False
+        self._flagged: Dict[int, str] = {}   # rows whose device state must be repaired before the next launch
+        self._void: set = set()              # rows for which the step in flight is void
 
     def any_active(self) -> bool:
         return any(r.active for r in self.rows)
@@ -427,13 +446,45 @@ class DecodeSession:
                 return int(tok.item())
         return resample
 
+    # ---- device-side repairs, applied only while the loop's stream is idle
+    def _repair_rows(self) -> None:
+        pipe, loop, rt = self.pipe, self.loop, self.rt
+        for b, what in self._flagged.items():
+            r = self.rows[b]
+            if what == "resync" and r.active:      # the host rules rewrote the row: rebuild its caches
+                pipe._prefill_row(rt, b, r.seq)
+                loop.join_current_stream()
+            pipe._set_row(loop, b, r)              # (re)position, or freeze a finished row
+        self._flagged.clear()
+
+    def _launch(self) -> None:
+        self._repair_rows()
+        self.loop.step(use_graph=True)
+        self._inflight = True
+        self._void = set()
+
+    def _next_step_is_needed(self) -> bool:
+        """Conservative: some row cannot finish in the step whose record is about to be processed."""
+        per_step = self.k + 1 if self.emit_mode == HipSpecDec.EMIT_BONUS else self.k
+        for b, r in enumerate(self.rows):
+            if not r.active or b in self._flagged:
+                continue
+            if len(r.generated) + per_step >= self.max_tokens:
+                continue
+            if self.step_limit is not None and r.steps + 2 > self.step_limit:
+                continue
+            if len(r.seq) + 3 * self.k + 6 > self.rt["l_max"]:
+                continue
+            return True
+        return False
+
     def advance(self) -> bool:
         """One draft-then-verify step for every active row. Returns False when the controller
         stops the run."""
         pipe, rows, stats = self.pipe, self.rows, self.stats
         self.step += 1
         step = self.step
-        if step > 1:
+        if step > 1 and not self._early:
             ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
                    "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
             k_new = int(pipe.controller.get_k(step, ctx))
@@ -441,6 +492,7 @@ class DecodeSession:
                 return False
             if k_new != self.k:  # adaptive K: another captured step over the same caches
                 self.loop.sync()
+                self._repair_rows()
                 self.k = k_new
                 self.rt, self.loop = pipe._runtime(len(rows), self.need, self.k, self.emit_mode)
                 self.loop.join_current_stream()
@@ -449,12 +501,20 @@ class DecodeSession:
                 self._apply_sampling()
         k, loop, rt = self.k, self.loop, self.rt
         t0 = time.time()
-        loop.step(use_graph=True)
+        if not self._inflight:
+            self._launch()
         rec = loop.sync()
+        self._inflight = False
+        void = self._void
         self.last_record = rec
+        if self._early and self._next_step_is_needed():
+            self._launch()          # step s+1 runs while the rules of step s are applied below
         stats["device_ms"] += (time.time() - t0) * 1e3
         for b, r in enumerate(rows):
             if not r.active:
+                continue
+            if b in void:           # launched before the host repaired this row: nothing to take from it
+                stats["void_row_steps"] += 1
                 continue
             a = int(rec.accept_len[b])
             t = [int(x) for x in rec.target_ids[b]]
@@ -470,18 +530,26 @@ class DecodeSession:
                     r.draws += 1
             else:
                 pipe._rules_single(r, k, a, d, t, self.max_tokens, self.eos)
+            r.steps += 1
             stats["proposed"] += k
             stats["accepted"] += r.accepted - acc0
-            if not r.active:
-                pipe._set_row(loop, b, r)       # freeze the row on the device
-            elif r.seq != assumed:
-                stats["resyncs"] += 1           # the host rules rewrote the row: rebuild its caches
-                loop.sync()
-                pipe._prefill_row(rt, b, r.seq)
-                loop.join_current_stream()
-                pipe._set_row(loop, b, r)
+            if r.active and self.step_limit is not None and r.steps >= self.step_limit:
+                r.active = False                # the reference's loop bound counts steps (pipeline.py:1984, :984)
             if r.active and len(r.seq) + 2 * k + 4 > rt["l_max"]:
                 r.active = False
-                pipe._set_row(loop, b, r)
-        stats["steps"] = step
+            if not r.active:
+                self._flagged[b] = "freeze"     # stop the row on the device
+            elif r.seq != assumed:
+                stats["resyncs"] += 1
+                self._flagged[b] = "resync"
+            if b in self._flagged and self._inflight:
+                self._void.add(b)
+        stats["steps"] = max(r.steps for r in rows)
         return True
+
+    def finish(self) -> None:
+        """Drain a step launched ahead of a run that ended, and leave the device rows consistent."""
+        if self._inflight:
+            self.loop.sync()
+            self._inflight = False
+        self._repair_rows()
