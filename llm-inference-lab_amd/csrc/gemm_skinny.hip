@@ -22,7 +22,7 @@
 
 namespace sd {
 
-constexpr int kSkBatch = 4;       // weight steps per batch (two batches in flight)
+template <int TG> struct SkBatch { static constexpr int value = (TG == 1) ? 8 : 4; };  // weight steps per batch (two batches in flight)
 constexpr int kSkMaxKc = 2048;
 
 struct SkinnyGeom {
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
   // wave-local step s (chunk-major) -> global step
   auto gstep = [&](int s) { return ((s >> sc_shift) * ksplit + kpart) * sc + (s & (sc - 1)); };
 
+  constexpr int kSkBatch = SkBatch<TG>::value;
   u32x4 bufA[kSkBatch], bufB[kSkBatch];
   auto issue = [&](u32x4 (&buf)[kSkBatch], const uint16_t* ts, int s0) {
 #pragma unroll
@@ -482,7 +483,9 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
   const int TG = (a.T + 15) / 16;
   // un-normalised, single-round shapes (out / down projections): operands straight to registers
-  if (a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
+  // (measured on the 3B shapes: ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads
+  // touch 16 rows x 64 bytes per instruction)
+  if (TG == 1 && a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
     if (epi == EPI_RESID) return launch_direct<EPI_RESID>(a, q.grid, st);
   }
   const size_t smem = skinny_smem(a.T, TG, sg.kc);
