@@ -27,6 +27,8 @@
 // All K and V loads of a block are issued before any arithmetic: one memory round
 // trip per block, and at decode lengths (<= 128 keys per wave) one per kernel.
 
+#include <stdlib.h>
+
 #include "attention_device.h"
 
 namespace sd {
@@ -34,10 +36,16 @@ namespace sd {
 template <int D>
 __global__ __launch_bounds__(kAttnThreads) void attention_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  attention_tile<D>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem, true);
+  const int ns = a.n_split > 1 ? a.n_split : 1;
+  attention_tile<D>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);
 }
 
-int launch_attention(const AttnArgs& a, hipStream_t st) {
+size_t attention_split_ws_bytes(int head_dim) {
+  return static_cast<size_t>(kAttnSplitSlots) * kAttnRows * (head_dim + 2) * sizeof(float) + static_cast<size_t>(kAttnSplitSlots) * sizeof(unsigned);
+}
+
+int launch_attention(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
   SD_REQUIRE(a.head_dim == 32 || a.head_dim == 64 || a.head_dim == 128,
              "attention: head_dim %d not in {32,64,128}", a.head_dim);
   SD_REQUIRE(a.n_kv_heads > 0 && a.n_q_heads % a.n_kv_heads == 0, "attention: Hq %% Hkv != 0");
@@ -48,7 +56,20 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   const int tiles = (R + kAttnRows - 1) / kAttnRows;
   const int D = a.head_dim;
   const size_t smem = attention_smem_bytes(D);
-  const dim3 grid(a.n_kv_heads, a.B, tiles), block(kAttnThreads);
+  // split-KV: as many workgroups per tile as the cache could keep busy (one per 256 keys of l_max),
+  // within the partial-tile workspace and ~one wave of workgroups over the chip; the kernel uses
+  // fewer while the row is short. Fixed per launch site, so a captured step stays valid as rows grow.
+  const int base = a.n_kv_heads * a.B * tiles;
+  int ns = 1;
+  if (a.split_ws && a.split_cnt && !getenv("SPECDEC_NO_ATTN_SPLIT")) {
+    ns = a.l_max / (kAttnBlock * kAttnSplitBlocks);
+    if (ns > kAttnMaxSplit) ns = kAttnMaxSplit;
+    if (ns > a.split_slots / base) ns = a.split_slots / base;
+    if (ns > 512 / base) ns = 512 / base;
+    if (ns < 1) ns = 1;
+  }
+  a.n_split = ns;
+  const dim3 grid(a.n_kv_heads, a.B, tiles * ns), block(kAttnThreads);
   switch (D) {
     case 32: hipLaunchKernelGGL(attention_mfma_kernel<32>, grid, block, smem, st, a); break;
     case 64: hipLaunchKernelGGL(attention_mfma_kernel<64>, grid, block, smem, st, a); break;

@@ -10,6 +10,8 @@ constexpr int kAttnThreads = 256;
 constexpr int kAttnWaves = 4;
 constexpr int kAttnRows = 16;    // query rows per workgroup (MFMA tile)
 constexpr int kAttnBlock = 32;   // keys per block
+constexpr int kAttnSplitBlocks = 16;  // a workgroup is worth adding per this many key blocks (512 keys)
+constexpr int kAttnMaxSplit = 32;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -21,9 +23,14 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 // One (batch row, kv head, 16-query-row tile). Called by a whole workgroup; only the threads
 // with `active` (the first 256 = 4 waves) compute, every thread takes the one barrier.
+// With a.n_split > 1 the keys of a tile are shared by up to n_split workgroups (`split` = this one's
+// index): the number actually used, s_eff, follows the row's current length (one workgroup per 512
+// keys), the others leave at once. Each computes an un-normalised partial over its blocks; the last to
+// arrive (device-scope counter) merges them — flash-decoding across CUs, for contexts where one
+// workgroup per kv head would walk thousands of keys while 248 CUs idle.
 template <int D>
 __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b, int tile, unsigned char* smem,
-                                               bool active) {
+                                               bool active, int split = 0) {
   constexpr int NKS = D / 32;  // k-steps of the QK^T contraction
   constexpr int NDT = D / 16;  // 16-wide tiles of the output channels
   const int G = a.n_q_heads / a.n_kv_heads, M = a.M;
@@ -40,6 +47,11 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
   const int pos0 = a.pos_base[b] + a.pos_off;             // position of query m = 0
   const int n_keys = max(0, min(pos0 + M, a.l_max));      // keys visible to the last query
   const int n_blocks = (n_keys + kAttnBlock - 1) / kAttnBlock;
+  int s_eff = 1;
+  if (a.n_split > 1) {
+    s_eff = min(a.n_split, max(1, (n_blocks + kAttnSplitBlocks - 1) / kAttnSplitBlocks));
+    if (split >= s_eff) return;  // workgroup-uniform, before any barrier
+  }
 
   // ---- Q fragments: lane (g, n) holds Q[row n][32 s + 8 g .. +8] for s < NKS -------
   const int qstride = a.n_q_heads * D;
@@ -69,7 +81,7 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
 
   const int my_limit = pos0 + my_m;  // last key this lane's query may see
 
-  for (int blk = active ? wave : n_blocks; blk < n_blocks; blk += kAttnWaves) {
+  for (int blk = active ? split * kAttnWaves + wave : n_blocks; blk < n_blocks; blk += kAttnWaves * s_eff) {
     const int key0 = blk * kAttnBlock;
     // ---- issue every load of the block -------------------------------------------
     // S^T tile u (u = 0,1): MFMA row i (= lane n) is key  key0 + 8*(i>>2) + 4*u + (i&3)
@@ -163,6 +175,80 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
   }
   __syncthreads();
   uint16_t* out = static_cast<uint16_t*>(a.out);
+  if (s_eff > 1) {
+    // ---- partial of this workgroup -> workspace; the last arrival merges all s_eff partials
+    const int tiles = (R + kAttnRows - 1) / kAttnRows;
+    const int group = (b * a.n_kv_heads + kvh) * tiles + tile;
+    constexpr int PS = kAttnRows * (D + 2);  // floats per partial: O[16][D], max[16], sum[16]
+    float* mine = a.split_ws + (static_cast<size_t>(group) * a.n_split + split) * PS;
+    for (int i = tid; i < kAttnRows * D; i += kAttnThreads) {
+      const int r = i / D, d = i - r * D;
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < kAttnWaves; ++w) mm = fmaxf(mm, m_s[w * kAttnRows + r]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int w = 0; w < kAttnWaves; ++w) {
+        const float mw = m_s[w * kAttnRows + r];
+        const float f = (mw > -INFINITY) ? __expf(mw - mm) : 0.f;
+        num += f * o_s[(w * kAttnRows + r) * D + d];
+        den += f * l_s[w * kAttnRows + r];
+      }
+      mine[i] = num;
+      if (d == 0) {
+        mine[kAttnRows * D + r] = mm;
+        mine[kAttnRows * D + kAttnRows + r] = den;
+      }
+    }
+    __threadfence();       // release the partial at device scope ...
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(m_s);  // LDS scratch (m_s is dead after the loop above)
+    if (tid == 0) {
+      const unsigned old = atomicAdd(a.split_cnt + group, 1u);   // ... before the arrival is counted
+      *flag = (old == static_cast<unsigned>(s_eff - 1)) ? 1u : 0u;
+      if (old == static_cast<unsigned>(s_eff - 1)) a.split_cnt[group] = 0u;  // ready for the next launch
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    __threadfence();       // acquire: the other workgroups' partials
+    const float* base = a.split_ws + static_cast<size_t>(group) * a.n_split * PS;
+    // (max, sum) of every partial into LDS, then each thread owns 8 consecutive channels of one row and
+    // streams its slice of the s_eff partial tiles with independent 16-byte loads
+    float* pm = o_s;                           // [s_eff][16] max   (o_s is dead: the partial has been written)
+    float* pl = o_s + kAttnMaxSplit * kAttnRows;  // [s_eff][16] sum
+    for (int i = tid; i < s_eff * kAttnRows; i += kAttnThreads) {
+      const int sidx = i / kAttnRows, r = i - sidx * kAttnRows;
+      pm[i] = base[static_cast<size_t>(sidx) * PS + kAttnRows * D + r];
+      pl[i] = base[static_cast<size_t>(sidx) * PS + kAttnRows * D + kAttnRows + r];
+    }
+    __syncthreads();
+    constexpr int CPR = D / 8;                 // 8-channel chunks per row
+    for (int c = tid; c < rows * CPR; c += kAttnThreads) {
+      const int r = c / CPR, d0 = (c - r * CPR) * 8;
+      float mm = -INFINITY;
+      for (int sidx = 0; sidx < s_eff; ++sidx) mm = fmaxf(mm, pm[sidx * kAttnRows + r]);
+      float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float den = 0.f;
+      const float* src = base + r * D + d0;
+#pragma unroll 4
+      for (int sidx = 0; sidx < s_eff; ++sidx) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + static_cast<size_t>(sidx) * PS);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + static_cast<size_t>(sidx) * PS + 4);
+        const float ms = pm[sidx * kAttnRows + r];
+        const float f = (ms > -INFINITY) ? __expf(ms - mm) : 0.f;
+        den += f * pl[sidx * kAttnRows + r];
+        num[0] += f * v0.x; num[1] += f * v0.y; num[2] += f * v0.z; num[3] += f * v0.w;
+        num[4] += f * v1.x; num[5] += f * v1.y; num[6] += f * v1.z; num[7] += f * v1.w;
+      }
+      const float inv = (den > 0.f) ? 1.0f / den : 0.f;
+      const int rr = r_base + r, gh = rr / M, m = rr - gh * M;
+      uint16_t* dst = out + static_cast<size_t>(b * M + m) * qstride + (kvh * G + gh) * D + d0;
+      const u32x4 o = {pack_bf16x2(num[0] * inv, num[1] * inv), pack_bf16x2(num[2] * inv, num[3] * inv),
+                       pack_bf16x2(num[4] * inv, num[5] * inv), pack_bf16x2(num[6] * inv, num[7] * inv)};
+      *reinterpret_cast<u32x4*>(dst) = o;
+    }
+    return;
+  }
   for (int i = active ? tid : rows * D; i < rows * D; i += kAttnThreads) {
     const int r = i / D, d = i - r * D;
     float mm = -INFINITY;

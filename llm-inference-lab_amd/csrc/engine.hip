@@ -35,6 +35,8 @@ struct sd_model {
   uint16_t* q = nullptr;     // [64][Hq*D]
   uint16_t* attn = nullptr;  // [64][Hq*D]
   uint16_t* act = nullptr;   // [64][ff]
+  float* attn_ws = nullptr;      // split-KV partial tiles (attention.hip)
+  unsigned* attn_cnt = nullptr;  // arrival counters, zero between launches
   float* part_val = nullptr; // [64][512]
   int small_t = sd::kGemvMaxT; // tokens per pass of gemv.hip for this model's widest activation row (<= 9)
   int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
@@ -61,6 +63,7 @@ static size_t workspace_bytes(const sd_model_config& c) {
   n += align_up(T * c.n_heads * c.head_dim * 2, 256) * 2;
   n += align_up(T * c.d_ff * 2, 256);
   n += align_up(T * kMaxPartials * 4, 256) * 2;
+  n += align_up(attention_split_ws_bytes(c.head_dim), 256);
   return n + 256;
 }
 
@@ -147,6 +150,9 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     at.head_dim = D;
     at.l_max = m->Lmax;
     at.scale = 1.0f / sqrtf(static_cast<float>(D));
+    at.split_ws = m->attn_ws;
+    at.split_cnt = m->attn_cnt;
+    at.split_slots = kAttnSplitSlots;
     if (int rc = launch_attention(at, st)) return rc;
 
     // 3. output projection + residual
@@ -393,6 +399,10 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->part_val = reinterpret_cast<float*>(p);
   p += align_up(T * kMaxPartials * 4, 256);
   m->part_idx = reinterpret_cast<int*>(p);
+  p += align_up(T * kMaxPartials * 4, 256);
+  m->attn_ws = reinterpret_cast<float*>(p);
+  m->attn_cnt = reinterpret_cast<unsigned*>(p + static_cast<size_t>(kAttnSplitSlots) * 16 * (c.head_dim + 2) * sizeof(float));
+  SD_HIP_CHECK(hipMemset(m->attn_cnt, 0, kAttnSplitSlots * sizeof(unsigned)));
   return 0;
 }
 

@@ -84,8 +84,16 @@ struct AttnArgs {
   int B, M;
   int n_q_heads, n_kv_heads, head_dim, l_max;
   float scale;
+  // split-KV over workgroups for long contexts (attention.hip): partial (max, sum, O) tiles and one
+  // arrival counter per (row, kv head, query tile); null / 0 = every tile is one workgroup
+  float* split_ws;
+  unsigned* split_cnt;
+  int split_slots;      // partial tiles the workspace holds
+  int n_split;          // set by launch_attention
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
+constexpr int kAttnSplitSlots = 1024;   // partial tiles of the split-KV workspace
+size_t attention_split_ws_bytes(int head_dim);   // workspace for kAttnSplitSlots partial tiles (+ counters)
 
 // ---- small kernels (misc.hip) -------------------------------------------------------
 struct EmbedArgs {

@@ -165,3 +165,42 @@ def test_batched_verify_shapes_on_synthetic_pair(B, M, monkeypatch):
         want, _ = lm.forward(s.view(1, -1))
         assert torch.equal(outs[None][b], want[0, lens[b]:].argmax(-1)), (B, M, b)
     assert torch.equal(outs[None], outs[9])
+
+
+@pytest.mark.parametrize("lens,M", [([300, 1500, 40], 5), ([2100], 1), ([900, 901], 9), ([700], 33)])
+def test_long_context_split_kv_attention(lens, M, monkeypatch):
+    """Contexts of hundreds to thousands of keys: the keys of a (row, kv head, query tile) are shared by
+    several workgroups (one per 256 keys of the row's CURRENT length, merged by the last arrival). Logits
+    against the oracle, and against the one-workgroup-per-tile path (SPECDEC_NO_ATTN_SPLIT)."""
+    import dataclasses
+
+    from helpers import TINY_TARGET
+    from specdec_hip import weights as W
+
+    tgt = W.synthetic_llama(dataclasses.replace(TINY_TARGET, max_pos=4096), seed=0, device="cpu", layer_gain=0.3)
+    lm = OracleLM(tgt, precision="bf16")
+    V, B = tgt.config.vocab, len(lens)
+    g = torch.Generator().manual_seed(sum(lens) + M)
+    seqs = [torch.randint(4, V, (n + M,), generator=g) for n in lens]
+    outs = {}
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("SPECDEC_NO_ATTN_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("SPECDEC_NO_ATTN_SPLIT", "1")
+        hm = _hip_model(tgt, batch=B, l_max=max(lens) + M + 64)
+        for b, (n, s) in enumerate(zip(lens, seqs)):
+            hm.forward(s[:n].to(torch.int32).view(1, -1).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), 0,
+                       skip_head=True, row0=b)
+        new = torch.stack([s[n:] for n, s in zip(lens, seqs)], 0)
+        ids, logits = hm.forward(new.to(torch.int32).cuda(), torch.tensor(lens, dtype=torch.int32, device="cuda"), 0, want_logits=True)
+        # a second forward at the same positions re-uses the arrival counters: they must be back at zero
+        ids2, logits2 = hm.forward(new.to(torch.int32).cuda(), torch.tensor(lens, dtype=torch.int32, device="cuda"), 0, want_logits=True)
+        assert torch.equal(ids, ids2) and torch.equal(logits, logits2)
+        outs[split] = (ids.cpu().long(), logits.float().cpu())
+    for b, (n, s) in enumerate(zip(lens, seqs)):
+        want, _ = lm.forward(s.view(1, -1))
+        want = want[0, n:]
+        assert _rel_err(outs[True][1][b], want) < 0.03, (lens, b)
+        assert torch.equal(outs[True][0][b], outs[True][1][b].argmax(-1))
+    assert _rel_err(outs[True][1], outs[False][1]) < 0.01
