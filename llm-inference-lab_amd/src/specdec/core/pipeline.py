@@ -403,6 +403,11 @@ class DecodeSession:
         self.need = max(len(r.seq) for r in self.rows) + max_tokens + 2 * int(k_max) + 8
         self.k = int(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
         self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode)
+        # positions a row may use: the cache rows and both models' position tables
+        self.pos_limit = min(self.rt["l_max"], pipe.base_lm.config.max_pos, pipe.draft_lm.config.max_pos)
+        for r in self.rows:
+            if len(r.seq) + 2 * self.k + 4 > self.pos_limit:
+                raise ValueError(f"prompt of {len(r.seq)} tokens leaves no room for a step within {self.pos_limit} positions")
         pipe._prefill(self.rt, self.rows)
         self.loop.join_current_stream()
         for b, r in enumerate(self.rows):
@@ -473,7 +478,7 @@ class DecodeSession:
                 continue
             if self.step_limit is not None and r.steps + 2 > self.step_limit:
                 continue
-            if len(r.seq) + 3 * self.k + 6 > self.rt["l_max"]:
+            if len(r.seq) + 3 * self.k + 6 > self.pos_limit:
                 continue
             return True
         return False
@@ -535,8 +540,8 @@ class DecodeSession:
             stats["accepted"] += r.accepted - acc0
             if r.active and self.step_limit is not None and r.steps >= self.step_limit:
                 r.active = False                # the reference's loop bound counts steps (pipeline.py:1984, :984)
-            if r.active and len(r.seq) + 2 * k + 4 > rt["l_max"]:
-                r.active = False
+            if r.active and len(r.seq) + 2 * k + 4 > self.pos_limit:
+                r.active = False                # out of cache rows / model positions
             if not r.active:
                 self._flagged[b] = "freeze"     # stop the row on the device
             elif r.seq != assumed:

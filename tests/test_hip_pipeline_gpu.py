@@ -169,3 +169,74 @@ def test_run_specdec_cli_prints_the_reference_json(capsys, monkeypatch):
                         "base_model", "draft_model", "draft_mode", "dtype"}
     assert out["impl"] == "hip" and out["proposed"] > 0 and len(out["text"].split()) == 12
     assert run_specdec.main(["--prompt", "5 6", "--K", "2", "--adaptive-K"]) == 1
+
+
+def _oracle_pair(drf, tgt, k, eos):
+    return OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=k, eos_token_id=eos)
+
+
+@pytest.mark.parametrize("eos_at", [3, 4, 7, 8])
+def test_eos_inside_accepted_tokens_and_as_bonus(eos_at):
+    """The EOS rules of the reference (accepted EOS is cut and stops the row, a bonus EOS is kept,
+    pipeline.py:3120-3131, :3274-3280): make the eos_at-th token of the greedy continuation the EOS id, so it
+    lands at different offsets inside a step (accepted prefix, bonus position, first token)."""
+    from src.specdec import HipLM, SpeculativePipeline
+    from src.specdec.models.hip_lm import IdTokenizer
+
+    drf, tgt = tiny_pair(flip_fraction=0.1)
+    V = tgt.config.vocab
+    prompts = synthetic_prompts(2, 9, V).tolist()
+    free = _oracle_pair(drf, tgt, 4, None).generate_batch(prompts, 16)
+    eos = free[0]["generated_tokens"][eos_at]
+    want = _oracle_pair(drf, tgt, 4, eos).generate_batch(prompts, 16)
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt.to("cuda"), tokenizer=IdTokenizer(V, eos_token_id=eos)), draft_lm=HipLM(drf.to("cuda")),
+                               controller="fixed", controller_params={"k": 4}, seed=1234)
+    got = pipe.generate_batch(prompts, max_tokens=16, do_sample=False)
+    for b in range(2):
+        assert got[b]["generated_tokens"] == want[b]["generated_tokens"], (eos_at, b)
+        assert (got[b]["proposed"], got[b]["accepted"], got[b]["sequence"]) == (want[b]["proposed"], want[b]["accepted"], want[b]["sequence"])
+    assert len(want[0]["generated_tokens"]) < 16     # the row did stop at the EOS
+    single = pipe.generate(prompts[0], max_tokens=16, do_sample=False)
+    ws = _oracle_pair(drf, tgt, 4, eos).generate(prompts[0], 16)
+    assert single["generated_tokens"] == ws["generated_tokens"] and single["steps"] == ws["steps"]
+
+
+@pytest.mark.parametrize("plen,max_tokens,k", [(1, 6, 4), (2, 5, 2), (5, 1, 4), (5, 2, 8), (3, 3, 1)])
+def test_tiny_prompts_and_budgets(plen, max_tokens, k):
+    """One- and two-token prompts (no `prev` token for the first draft pass), budgets smaller than K."""
+    drf, tgt = tiny_pair(flip_fraction=0.25)
+    V = tgt.config.vocab
+    prompts = synthetic_prompts(3, plen, V).tolist()
+    pipe = _pipe(drf, tgt, k)
+    oracle = _oracle_pair(drf, tgt, k, tgt.config.eos_token_id)
+    got = pipe.generate_batch(prompts, max_tokens=max_tokens, do_sample=False)
+    want = oracle.generate_batch(prompts, max_tokens)
+    for b in range(3):
+        assert got[b]["generated_tokens"] == want[b]["generated_tokens"], (plen, max_tokens, k, b)
+        assert (got[b]["proposed"], got[b]["accepted"]) == (want[b]["proposed"], want[b]["accepted"])
+    gs, ws = pipe.generate(prompts[0], max_tokens=max_tokens, do_sample=False), oracle.generate(prompts[0], max_tokens)
+    assert gs["generated_tokens"] == ws["generated_tokens"] and (gs["proposed"], gs["accepted"]) == (ws["proposed"], ws["accepted"])
+
+
+def test_position_limit_stops_rows_without_faults():
+    """A row that reaches the model's position limit / cache capacity is stopped by the host before the device
+    could index past them; the tokens emitted until then are the oracle's."""
+    import dataclasses
+
+    from helpers import TINY_DRAFT, TINY_TARGET
+    from specdec_hip import weights as W
+
+    tcfg, dcfg = dataclasses.replace(TINY_TARGET, max_pos=96), dataclasses.replace(TINY_DRAFT, max_pos=96)
+    tgt = W.synthetic_llama(tcfg, seed=0, device="cpu")
+    drf = W.synthetic_llama(dcfg, seed=1, device="cpu", embed_from=tgt, flip_fraction=0.25)
+    prompts = synthetic_prompts(2, 40, tgt.config.vocab).tolist()
+    pipe = _pipe(drf, tgt, 4)
+    got = pipe.generate_batch(prompts, max_tokens=200, do_sample=False)     # would need 240 positions; the models have 96
+    lm = OracleLM(tgt, "bf16")
+    for b in range(2):
+        g = got[b]["generated_tokens"]
+        assert 30 <= len(g) and len(prompts[b]) + len(g) <= 96
+        want, _ = lm.generate_tokens(torch.tensor([prompts[b]]), len(g))
+        assert g == want[0].tolist()
+    with pytest.raises(ValueError, match="no room"):
+        pipe.generate_batch([list(range(4, 94))], max_tokens=4, do_sample=False)
