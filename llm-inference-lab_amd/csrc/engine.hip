@@ -319,11 +319,12 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
     const sd_model_config& c = m->cfg;
     const bool llama = (c.arch == SD_ARCH_LLAMA);
     const int HqD = c.n_heads * c.head_dim;
-    const bool ok = gemm_skinny_covers(kSkinnyMaxT, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model) &&
-                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, HqD) &&
-                    gemm_skinny_covers(kSkinnyMaxT, llama ? c.d_ff : c.d_ff / 2, c.d_model) &&
-                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, c.d_ff) &&
-                    gemm_skinny_covers(kSkinnyMaxT, (c.vocab + 1) / 2, c.d_model);
+    const bool w8 = cfg->weight_dtype == SD_FP8_E4M3;
+    const bool ok = gemm_skinny_covers(kSkinnyMaxT, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model, w8) &&
+                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, HqD, w8) &&
+                    gemm_skinny_covers(kSkinnyMaxT, llama ? c.d_ff : c.d_ff / 2, c.d_model, w8) &&
+                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, c.d_ff, w8) &&
+                    gemm_skinny_covers(kSkinnyMaxT, (c.vocab + 1) / 2, c.d_model, w8);
     const char* env = getenv("SPECDEC_MAX_PASS_TOKENS");  // testing knob: 9 forces the small-T kernel everywhere
     int want = env ? atoi(env) : kSkinnyMaxT;
     if (want > kSkinnyMaxT) want = kSkinnyMaxT;
@@ -331,7 +332,7 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
     if (c.d_ff > kmax) kmax = c.d_ff;
     m->small_t = gemv_max_tokens(kmax);  // e.g. 5 for d_ff = 14336: x rows must fit the CU's LDS
     if (want < m->small_t) want = m->small_t;
-    m->max_t = (ok && cfg->weight_dtype == SD_BF16) ? want : m->small_t;  // the multi-token kernel streams bf16 only
+    m->max_t = ok ? want : m->small_t;
   }
   if (cfg->weight_dtype == SD_FP8_E4M3) {
     // every matrix must split into whole 64-k steps per K slice

@@ -38,11 +38,12 @@ static size_t skinny_smem(int T, int TG, int kc) {
 }
 
 // chunk width for (T, K, ksplit), or 0 when the shape is not covered
-static int skinny_chunk(int T, int K, int ksplit, int kw) {
-  if (K % 32 != 0 || kw * ksplit != K) return 0;
+static int skinny_chunk(int T, int K, int ksplit, int kw, bool w8 = false) {
+  const int ks = w8 ? 64 : 32;   // k covered by one 16-byte weight load
+  if (K % ks != 0 || kw % ks != 0 || kw * ksplit != K) return 0;
   const int TG = (T + 15) / 16;
   int best = 0;
-  for (int kc = 32 * ksplit; kc <= kSkMaxKc; kc <<= 1) {
+  for (int kc = ks * ksplit; kc <= kSkMaxKc; kc <<= 1) {
     if (K % kc != 0) break;
     if (skinny_smem(T, TG, kc) > 160 * 1024) break;
     best = kc;
@@ -50,8 +51,11 @@ static int skinny_chunk(int T, int K, int ksplit, int kw) {
   return best;
 }
 
-template <int EPI, int TG>
+// W8: fp8 e4m3 weight storage (csrc/pack.hip) — a "step" is then one 16-byte load = 64 k = two MFMAs per
+// token group, widened to bf16 in registers as in gemv.hip; the row sum is scaled in the epilogue.
+template <int EPI, int TG, bool W8>
 __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArgs a, const SkinnyGeom sg) {
+  constexpr int KS = W8 ? 64 : 32;   // k per weight step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
   const int kc = sg.kc, KP = kc + kXPad;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
   const int tiles_per_round = kGemvWaves / ksplit;
   const int kpart = wave & (ksplit - 1);
   const int tslot = wave / ksplit;
-  const int steps_w = a.kw >> 5;                 // steps of one wave over the whole K
+  const int steps_w = a.kw / KS;                 // steps of one wave over the whole K
   const int sc_shift = sg.sc_shift, sc = 1 << sc_shift;
   const uint16_t* W = static_cast<const uint16_t*>(a.W);
 
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
       if (jp >= np) { jp = 0; second = 0; }
       wstride = np * 64;
       lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
-      return W + static_cast<size_t>(p0) * 2 * K;
+      return W + static_cast<size_t>(p0) * (W8 ? 1 : 2) * K;   // in 2-byte units: one byte per fp8 weight
     }
     int p = p0 + (n & 7);
     int second = n >> 3;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
 #pragma unroll
   for (int q = 0; q < TG; ++q) {
     const int t = 16 * q + n;
-    xrow_off[q] = (t < T ? t : T - 1) * KP + kpart * sc * 32 + g * 8;
+    xrow_off[q] = (t < T ? t : T - 1) * KP + kpart * sc * KS + g * 8;
   }
 
   for (int r = 0; r < rounds; ++r) {
@@ -221,12 +225,30 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
             __syncthreads();
           }
           if (valid) {
-            const int koff = (s & (sc - 1)) * 32;
+            const int koff = (s & (sc - 1)) * KS;
+            if constexpr (W8) {
+              u32x4 lo, hi;
 #pragma unroll
-            for (int q = 0; q < TG; ++q) {
-              const u32x4 xb = *reinterpret_cast<const u32x4*>(xs + xrow_off[q] + koff);
-              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
-                                                               __builtin_bit_cast(bf16x8_t, xb), acc[q], 0, 0, 0);
+              for (int e = 0; e < 2; ++e) {
+                lo[2 * e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][e], 1.0f, false));
+                lo[2 * e + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][e], 1.0f, true));
+                hi[2 * e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][2 + e], 1.0f, false));
+                hi[2 * e + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(buf[j][2 + e], 1.0f, true));
+              }
+#pragma unroll
+              for (int q = 0; q < TG; ++q) {
+                const u32x4 xb0 = *reinterpret_cast<const u32x4*>(xs + xrow_off[q] + koff);
+                const u32x4 xb1 = *reinterpret_cast<const u32x4*>(xs + xrow_off[q] + koff + 32);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, lo), __builtin_bit_cast(bf16x8_t, xb0), acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hi), __builtin_bit_cast(bf16x8_t, xb1), acc[q], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < TG; ++q) {
+                const u32x4 xb = *reinterpret_cast<const u32x4*>(xs + xrow_off[q] + koff);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[j]),
+                                                                 __builtin_bit_cast(bf16x8_t, xb), acc[q], 0, 0, 0);
+              }
             }
           }
         }
@@ -263,6 +285,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
             for (int w = 0; w < ksplit; ++w) {
               y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
               y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
+            }
+            if constexpr (W8) {
+              y0 *= a.w_scale[r0];
+              y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;
             }
             epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
           }
@@ -435,33 +461,38 @@ static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
-template <int EPI, int TG>
+template <int EPI, int TG, bool W8>
 static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG>),
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG, W8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG, W8>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
-template <int EPI>
-static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
+template <int EPI, bool W8>
+static int launch_skinny_w(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
   switch ((a.T + 15) / 16) {
-    case 1: return launch_skinny_one<EPI, 1>(a, sg, grid, smem, st);
-    case 2: return launch_skinny_one<EPI, 2>(a, sg, grid, smem, st);
-    case 3: return launch_skinny_one<EPI, 3>(a, sg, grid, smem, st);
-    default: return launch_skinny_one<EPI, 4>(a, sg, grid, smem, st);
+    case 1: return launch_skinny_one<EPI, 1, W8>(a, sg, grid, smem, st);
+    case 2: return launch_skinny_one<EPI, 2, W8>(a, sg, grid, smem, st);
+    case 3: return launch_skinny_one<EPI, 3, W8>(a, sg, grid, smem, st);
+    default: return launch_skinny_one<EPI, 4, W8>(a, sg, grid, smem, st);
   }
 }
 
-bool gemm_skinny_covers(int T, int n_pairs, int K) {
+template <int EPI>
+static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
+  return a.w8 ? launch_skinny_w<EPI, true>(a, sg, grid, smem, st) : launch_skinny_w<EPI, false>(a, sg, grid, smem, st);
+}
+
+bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8) {
   if (T < 1 || T > kSkinnyMaxT || n_pairs < 1) return false;
   const GemvGeom q = gemv_geometry(n_pairs, K);
-  return skinny_chunk(T, K, q.ksplit, q.kw) != 0;
+  return skinny_chunk(T, K, q.ksplit, q.kw, w8) != 0;
 }
 
 int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
@@ -469,23 +500,23 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   SD_REQUIRE(a.T >= 1 && a.T <= kSkinnyMaxT, "gemm_skinny: T=%d out of range 1..%d", a.T, kSkinnyMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemm_skinny: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
   SD_REQUIRE(a.n_pairs > 0, "gemm_skinny: no rows");
-  SD_REQUIRE(!a.w8, "gemm_skinny: fp8 weights are streamed by gemv.hip only (<= 9 tokens per pass)");
+  SD_REQUIRE(!a.w8 || (a.packed && a.w_scale), "gemm_skinny: fp8 weights need the packed layout and row scales");
   const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
   a.ppw = q.ppw;
   a.tile_pairs = q.tile_pairs;
   a.ksplit = q.ksplit;
   a.kw = q.kw;
   SkinnyGeom sg{};
-  sg.kc = skinny_chunk(a.T, a.K, q.ksplit, q.kw);
+  sg.kc = skinny_chunk(a.T, a.K, q.ksplit, q.kw, a.w8 != 0);
   SD_REQUIRE(sg.kc != 0, "gemm_skinny: shape T=%d K=%d (ksplit %d) is not covered", a.T, a.K, q.ksplit);
-  const int sc = sg.kc / (32 * q.ksplit);
+  const int sc = sg.kc / ((a.w8 ? 64 : 32) * q.ksplit);
   sg.sc_shift = 0;
   while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
   const int TG = (a.T + 15) / 16;
   // un-normalised, single-round shapes (out / down projections): operands straight to registers
   // (measured on the 3B shapes: ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads
   // touch 16 rows x 64 bytes per instruction)
-  if (TG == 1 && a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
+  if (TG == 1 && !a.w8 && a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
     if (epi == EPI_RESID) return launch_direct<EPI_RESID>(a, q.grid, st);
   }
   const size_t smem = skinny_smem(a.T, TG, sg.kc);

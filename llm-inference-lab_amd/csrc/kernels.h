@@ -71,7 +71,7 @@ int gemv_grid(const GemvArgs& a, int* ppw_out);
 int gemv_max_tokens(int K);                                          // tokens gemv.hip can stage for rows of K elements (<= 9)
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip
 int launch_gemm_skinny(const GemvArgs& a, int epi, hipStream_t st);   // T <= 64
-bool gemm_skinny_covers(int T, int n_pairs, int K);                  // shape handled by gemm_skinny.hip
+bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8 = false);                  // shape handled by gemm_skinny.hip
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------
 struct AttnArgs {

@@ -30,16 +30,19 @@ def test_quantizer_is_bit_exact(N, K, scale):
     assert torch.equal(q.cpu().view(torch.uint8), want_q.view(torch.uint8))
 
 
-@pytest.mark.parametrize("name", ["llama", "gpt2"])
-def test_fp8_forward_matches_oracle_over_dequantized_weights(name):
+@pytest.mark.parametrize("name,L", [("llama", None), ("gpt2", None), ("llama", 5), ("llama", 40), ("gpt2", 64)])
+def test_fp8_forward_matches_oracle_over_dequantized_weights(name, L):
+    """L = None: the golden prompt; 5: one gemv.hip pass; 40 / 64: the multi-token kernel streaming fp8."""
     from specdec_hip.engine import HipModel
 
     mw, toks, _ = load_hf_golden(name, dtype=torch.bfloat16)
+    if L is not None:
+        toks = torch.randint(0, mw.config.vocab, (2, L), generator=torch.Generator().manual_seed(L))
     B, L = toks.shape
     want8, _ = OracleLM(fp8_ref.dequantized(mw), precision="bf16").forward(toks)
     want16, _ = OracleLM(mw, precision="bf16").forward(toks)
     hm = HipModel(mw.to("cuda"), batch=B, l_max=128, weight_dtype="fp8")
-    assert hm.pass_tokens == 9
+    assert hm.pass_tokens == 64
     ids, logits = hm.forward(toks.to(torch.int32).cuda(), torch.zeros(B, dtype=torch.int32, device="cuda"), 0, want_logits=True)
     got = logits.float().cpu()
     e8, gap = _rel_err(got, want8), _rel_err(want8, want16)
