@@ -33,11 +33,30 @@
 
 namespace sd {
 
-template <int D>
-__global__ __launch_bounds__(kAttnThreads) void attention_mfma_kernel(const AttnArgs a) {
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ns = a.n_split > 1 ? a.n_split : 1;
-  attention_tile<D>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);
+  attention_tile<D, NW>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);
+}
+
+template <int D, int NW>
+static void launch_attention_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t smem = attention_smem_bytes(D, NW);
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_mfma_kernel<D, NW>), grid, dim3(NW * 64), smem, st, a);
+}
+
+template <int D>
+static void launch_attention_d(const AttnArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (waves <= 4) launch_attention_one<D, 4>(a, grid, st);
+  else if (waves <= 8) launch_attention_one<D, 8>(a, grid, st);
+  else launch_attention_one<D, 16>(a, grid, st);
 }
 
 size_t attention_split_ws_bytes(int head_dim) {
@@ -55,7 +74,11 @@ int launch_attention(const AttnArgs& a_in, hipStream_t st) {
   const int R = G * a.M;
   const int tiles = (R + kAttnRows - 1) / kAttnRows;
   const int D = a.head_dim;
-  const size_t smem = attention_smem_bytes(D);
+  // 4 waves per workgroup. 8 and 16 (SPECDEC_ATTN_WAVES, kept for experiments) were measured and lose at every
+  // context length: the LDS merge grows with the wave count and a 16-wave workgroup holds a CU's LDS alone
+  // (3B + 1B, K=4: 8 K context 6.8 ms/step with 4 waves, 9.3 with 16; short contexts equal within noise).
+  int waves = 4;
+  if (const char* e = getenv("SPECDEC_ATTN_WAVES")) waves = atoi(e);
   // split-KV: as many workgroups per tile as the cache could keep busy (one per 256 keys of l_max),
   // within the partial-tile workspace and ~one wave of workgroups over the chip; the kernel uses
   // fewer while the row is short. Fixed per launch site, so a captured step stays valid as rows grow.
@@ -69,11 +92,11 @@ int launch_attention(const AttnArgs& a_in, hipStream_t st) {
     if (ns < 1) ns = 1;
   }
   a.n_split = ns;
-  const dim3 grid(a.n_kv_heads, a.B, tiles * ns), block(kAttnThreads);
+  const dim3 grid(a.n_kv_heads, a.B, tiles * ns);
   switch (D) {
-    case 32: hipLaunchKernelGGL(attention_mfma_kernel<32>, grid, block, smem, st, a); break;
-    case 64: hipLaunchKernelGGL(attention_mfma_kernel<64>, grid, block, smem, st, a); break;
-    default: hipLaunchKernelGGL(attention_mfma_kernel<128>, grid, block, smem, st, a); break;
+    case 32: launch_attention_d<32>(a, waves, grid, st); break;
+    case 64: launch_attention_d<64>(a, waves, grid, st); break;
+    default: launch_attention_d<128>(a, waves, grid, st); break;
   }
   SD_LAUNCH_CHECK();
   return 0;

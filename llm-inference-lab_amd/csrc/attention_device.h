@@ -6,8 +6,7 @@
 
 namespace sd {
 
-constexpr int kAttnThreads = 256;
-constexpr int kAttnWaves = 4;
+constexpr int kAttnMaxWaves = 16;  // waves per workgroup: 4, 8 or 16 (template parameter NW)
 constexpr int kAttnRows = 16;    // query rows per workgroup (MFMA tile)
 constexpr int kAttnBlock = 32;   // keys per block
 constexpr int kAttnSplitBlocks = 16;  // a workgroup is worth adding per this many key blocks (512 keys)
@@ -21,16 +20,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return static_cast<uint32_t>(float_to_bf16_bits(lo)) | (static_cast<uint32_t>(float_to_bf16_bits(hi)) << 16);
 }
 
-// One (batch row, kv head, 16-query-row tile). Called by a whole workgroup; only the threads
-// with `active` (the first 256 = 4 waves) compute, every thread takes the one barrier.
+// One (batch row, kv head, 16-query-row tile). Called by a whole workgroup of NW waves, which split the
+// 32-key blocks round-robin; every thread takes the barriers.
 // With a.n_split > 1 the keys of a tile are shared by up to n_split workgroups (`split` = this one's
 // index): the number actually used, s_eff, follows the row's current length (one workgroup per 512
 // keys), the others leave at once. Each computes an un-normalised partial over its blocks; the last to
 // arrive (device-scope counter) merges them — flash-decoding across CUs, for contexts where one
 // workgroup per kv head would walk thousands of keys while 248 CUs idle.
-template <int D>
+template <int D, int NW>
 __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b, int tile, unsigned char* smem,
                                                bool active, int split = 0) {
+  constexpr int kAttnWaves = NW, kAttnThreads = NW * 64;
   constexpr int NKS = D / 32;  // k-steps of the QK^T contraction
   constexpr int NDT = D / 16;  // 16-wide tiles of the output channels
   const int G = a.n_q_heads / a.n_kv_heads, M = a.M;
@@ -269,8 +269,10 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
 }
 
 
-inline size_t attention_smem_bytes(int D) {
-  return sizeof(float) * (static_cast<size_t>(kAttnWaves) * kAttnRows * D + 2 * kAttnWaves * kAttnRows);
+inline size_t attention_smem_bytes(int D, int waves) {
+  size_t n = sizeof(float) * (static_cast<size_t>(waves) * kAttnRows * D + 2 * waves * kAttnRows);
+  const size_t merge = sizeof(float) * 2 * kAttnMaxSplit * kAttnRows;   // (max, sum) of the split-KV partials
+  return n > merge ? n : merge;
 }
 
 }  // namespace sd

@@ -11,8 +11,11 @@ from specdec_hip import weights as W  # noqa: E402
 from specdec_hip.engine import HipSpecDec  # noqa: E402
 from src.specdec import HipLM, SpeculativePipeline  # noqa: E402
 
-tgt = W.synthetic_llama(W.LLAMA_3_2_3B, seed=0, device="cuda")
-drf = W.synthetic_llama(W.LLAMA_3_2_1B, seed=1, device="cuda", embed_from=tgt, flip_fraction=0.2)
+import dataclasses  # noqa: E402
+
+# the presets carry 4096 positions (rope tables are [max_pos][D/2] fp32); the long-context rows need more
+tgt = W.synthetic_llama(dataclasses.replace(W.LLAMA_3_2_3B, max_pos=36864), seed=0, device="cuda")
+drf = W.synthetic_llama(dataclasses.replace(W.LLAMA_3_2_1B, max_pos=36864), seed=1, device="cuda", embed_from=tgt, flip_fraction=0.2)
 pipe = SpeculativePipeline(base_lm=HipLM(tgt), draft_lm=HipLM(drf), controller="fixed", controller_params={"k": 4}, seed=1234)
 for L in (32, 512, 2048, 8192, 32768):
     g = torch.Generator().manual_seed(L)
