@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: both models stream an OCP e4m3 copy of their Linear weights (per-row scales, bf16 activations and "
                          "MFMA); not the headline configuration (BASELINE config 2 is bf16), CPU parity leg uses the dequantised weights")
+    ap.add_argument("--draft-mode", choices=["vanilla", "medusa"], default="vanilla",
+                    help="medusa: BASELINE config 5's draft — Medusa-lite heads tied to the lm_head (the reference draftor's "
+                         "semantics: K copies of the target's next token), single-prompt generate() loop, no draft model")
     ap.add_argument("--do-sample", action="store_true",
                     help="sampled bonus token (T=0.7, top_k=50, top_p=0.9: the reference's default sampler) instead of greedy; "
                          "not the headline configuration (SPECDEC_DETERMINISTIC is greedy), no CPU parity leg")
@@ -160,16 +163,20 @@ def main():
     log(f"rank {rank}/{world}: building {args.target} + {args.draft} weights on {device}")
     drf, tgt, source = build_models(args, device)
     wd = args.weight_dtype
+    medusa = args.draft_mode == "medusa"
     pipe = SpeculativePipeline(base_lm=HipLM(tgt, weight_dtype=wd), draft_lm=HipLM(drf, weight_dtype=wd), controller="fixed",
-                               controller_params={"k": args.k}, seed=1234)
+                               controller_params={"k": args.k}, seed=1234, draft_mode=args.draft_mode)
+    if medusa:
+        args.cpu_baseline_steps = 0
     K, B = args.k, args.batch
     prompts = prompts_for(rank, B, tgt.config.vocab)
     total_steps = args.warmup + args.steps
     sampling = {"temperature": 0.7, "top_k": 50, "top_p": 0.9, "seed": 1234} if args.do_sample else None
     if sampling:
         args.cpu_baseline_steps = 0
-    sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1, emit_mode=HipSpecDec.EMIT_BONUS,
-                              sampling=sampling)
+    sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1,
+                              emit_mode=HipSpecDec.EMIT_DRAFT if medusa else HipSpecDec.EMIT_BONUS,
+                              sampling=sampling, self_draft=medusa)
 
     def barrier():
         if dist is not None:
@@ -192,7 +199,7 @@ def main():
     n_tok = sum(len(r.generated) for r in sess.rows) - n0
     proposed = sess.stats["proposed"] - p0
     accepted_ref = sum(r.accepted for r in sess.rows) - a0          # reference definition (bonus counted)
-    accepted_strict = accepted_ref - args.steps * B                  # draft tokens accepted only
+    accepted_strict = accepted_ref - (0 if medusa else args.steps * B)   # draft tokens accepted only (generate() counts no bonus)
     from specdec_hip.dist_stats import gather_stats
 
     # the one collective of the job: a 48-byte struct per rank, all-gathered over RCCL/xGMI
@@ -207,7 +214,7 @@ def main():
     prop = job.total("proposed")
     value = job.tokens_per_s()
     ms_per_step = t_max / args.steps * 1e3
-    bytes_step = K * drf.matmul_bytes() + tgt.matmul_bytes()
+    bytes_step = (2 * tgt.matmul_bytes()) if medusa else (K * drf.matmul_bytes() + tgt.matmul_bytes())
     if wd == "fp8":
         bytes_step //= 2      # one byte per weight (+ 4 bytes per output row of scales: < 0.1 %)
     out = {
@@ -215,7 +222,7 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
-        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}, "
+        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{', Medusa-lite tied heads (self-draft), generate() loop' if medusa else ''}, "
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},

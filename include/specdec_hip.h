@@ -268,7 +268,11 @@ enum sd_emit_mode {
 };
 
 /* Creation allocates the (tiny) device loop state and a pinned host mirror. Both
- * models must be bound with the same B. */
+ * models must be bound with the same B.
+ * draft == NULL selects the self-draft mode: Medusa-lite with heads tied to the lm_head, greedy — the
+ * reference draftor (src/specdec/modes/medusa.py:71-186) evaluates head 0 on the same last hidden state for
+ * all K proposals, i.e. proposes K copies of the target's own next token; the step is then one 1-token target
+ * forward + the K+1-token verify forward. */
 int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K, int emit_mode,
                       sd_specdec** out);
 int sd_specdec_destroy(sd_specdec* s);

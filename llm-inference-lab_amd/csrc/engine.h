@@ -26,6 +26,7 @@ struct SpecState {
 };
 
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);
+int launch_medusa_fill(const SpecState& s, hipStream_t st);
 int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st);
 int launch_accept_len(const SpecState& s, hipStream_t st);
 

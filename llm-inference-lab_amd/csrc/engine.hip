@@ -564,13 +564,19 @@ __global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t
 
 static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   const int B = s->B, K = s->K;
-  const bool two = (st_d != st_t);
+  const bool two = (st_d != st_t) && s->draft;
+  if (!s->draft) {
+    // self-draft (Medusa-lite, tied heads): the target's own next token, K times
+    if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, 1, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_t))
+      return rc;
+    if (int rc = launch_medusa_fill(s->st, st_t)) return rc;
+  }
   if (two) {
     SD_HIP_CHECK(hipEventRecord(s->ev_fork, st_t));
     SD_HIP_CHECK(hipStreamWaitEvent(st_d, s->ev_fork, 0));
   }
   // draft: forward 0 over (prev, last) at positions cur_len-1, cur_len; then one token each
-  for (int i = 0; i < K; ++i) {
+  for (int i = 0; s->draft && i < K; ++i) {
     const int M = (i == 0) ? 2 : 1;
     const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
     const int off = (i == 0) ? -1 : i;
@@ -604,12 +610,11 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
 
 extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K, int emit_mode, sd_specdec** out) {
   clear_error();
-  SD_REQUIRE(draft && target && out, "specdec_create: NULL argument");
+  SD_REQUIRE(target && out, "specdec_create: NULL argument");   // draft == NULL: self-draft (Medusa-lite, tied heads)
   SD_REQUIRE(B >= 1 && K >= 1 && K <= 8, "specdec_create: B=%d K=%d (K in 1..8)", B, K);
   SD_REQUIRE(B * (K + 1) <= 65535, "specdec_create: batch too large");
-  SD_REQUIRE(draft->B >= B && target->B >= B, "specdec_create: models must be bound with batch >= %d", B);
-  SD_REQUIRE(draft->cfg.vocab == target->cfg.vocab, "specdec_create: draft/target vocabularies differ (%d vs %d)",
-             draft->cfg.vocab, target->cfg.vocab);
+  SD_REQUIRE((!draft || draft->B >= B) && target->B >= B, "specdec_create: models must be bound with batch >= %d", B);
+  SD_REQUIRE(!draft || draft->cfg.vocab == target->cfg.vocab, "specdec_create: draft/target vocabularies differ");
   SD_REQUIRE(emit_mode == SD_EMIT_BONUS || emit_mode == SD_EMIT_DRAFT, "specdec_create: emit_mode %d", emit_mode);
   // verify of B rows must fit the passes of the target forward: any B works (tiled)
   sd_specdec* s = new (std::nothrow) sd_specdec();

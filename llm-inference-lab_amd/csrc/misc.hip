@@ -89,6 +89,26 @@ __global__ void draft_next_kernel(int M, int i, SpecState s) {
   s.next_tok[b] = d;
 }
 
+// Medusa-lite with heads tied to (or copied from) the lm_head, greedy (modes/medusa.py:71-186): every head
+// is the lm_head and the draftor re-uses head 0 on the SAME hidden state for all K proposals, so the draft is
+// K copies of the target's own next token (the argmax of the M = 1 forward that precedes this kernel).
+__global__ void medusa_fill_kernel(SpecState s) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.B) return;
+  const int d = s.draft_ids[b * 2];
+  for (int i = 0; i < s.K; ++i) {
+    s.draft_tok[b * s.K + i] = d;
+    s.verify_tok[b * (s.K + 1) + i + 1] = d;
+  }
+  s.next_tok[b] = d;
+}
+
+int launch_medusa_fill(const SpecState& s, hipStream_t st) {
+  hipLaunchKernelGGL(medusa_fill_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, s);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st) {
   hipLaunchKernelGGL(draft_next_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, M, i, s);
   SD_LAUNCH_CHECK();

@@ -191,15 +191,16 @@ class HipSpecDec:
 
     EMIT_BONUS, EMIT_DRAFT = 0, 1
 
-    def __init__(self, draft: HipModel, target: HipModel, batch: int, k: int, emit_mode: int = 0):
-        assert draft.device == target.device
+    def __init__(self, draft: Optional[HipModel], target: HipModel, batch: int, k: int, emit_mode: int = 0):
+        """draft=None: self-draft mode (Medusa-lite with heads tied to the lm_head, see sd_specdec_create)."""
+        assert draft is None or draft.device == target.device
         self.lib = _abi.load()
         self.draft, self.target = draft, target
         self.device = target.device
         self.B, self.K = int(batch), int(k)
         handle = _vp()
         with torch.cuda.device(self.device):
-            _abi.check(self.lib.sd_specdec_create(draft.handle, target.handle, self.B, self.K, int(emit_mode),
+            _abi.check(self.lib.sd_specdec_create(draft.handle if draft is not None else None, target.handle, self.B, self.K, int(emit_mode),
                                                   ctypes.byref(handle)), "sd_specdec_create")
         self.handle = handle
         # hipGraph capture is not allowed on the legacy default stream: the loop owns two

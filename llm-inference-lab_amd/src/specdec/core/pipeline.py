@@ -58,6 +58,7 @@ _DEFAULTS: Dict[str, Any] = {
     "log_level": "INFO",
     "verbose": False,
     "draft_mode": "vanilla",
+    "medusa": {"enabled": False, "num_heads": 2, "head_init": "tie", "temperature": 0.7, "top_p": 1.0},
 }
 
 
@@ -94,8 +95,16 @@ class SpeculativePipeline:
             # "fake" (FakeLM test double) and CPU/MPS implementations of the reference have no
             # counterpart here: the product is the GPU path
             raise ValueError(f"implementation={impl!r} is not available in this build (use 'hip')")
-        if draft_mode != "vanilla":
-            raise NotImplementedError(f"draft_mode={draft_mode!r}: only 'vanilla' drafting is on the HIP path")
+        mode = self.config.get("draft_mode", "vanilla")
+        if mode == "medusa":
+            # Medusa-lite as the reference's draftor defines it (modes/medusa.py): heads tied to / copied from the
+            # lm_head, head 0 evaluated on the same last hidden state for all K proposals -> K copies of the
+            # target's own next token. The pipeline's HF path re-creates RANDOM heads on every call
+            # (pipeline.py:689-705), which has no reproducible restatement; `head_init: random` is refused.
+            if self.config.get("medusa", {}).get("head_init", "tie") not in ("tie", "copy"):
+                raise NotImplementedError("draft_mode='medusa' needs medusa.head_init 'tie' or 'copy' (random heads are not restated)")
+        elif mode != "vanilla":
+            raise NotImplementedError(f"draft_mode={mode!r}: 'vanilla' and 'medusa' drafting are on the HIP path")
         if not torch.cuda.is_available():
             raise RuntimeError("SpeculativePipeline needs a GPU (PyTorch-ROCm device 'cuda'); there is no CPU path")
         self.device = "cuda"
@@ -107,12 +116,15 @@ class SpeculativePipeline:
         ensure_deterministic(int(self.config.get("seed") or 1234))
 
         self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
-        self.draft_lm = draft_lm if draft_lm is not None else create_hip_lm(self.config["draft_model"])
+        no_draft = mode == "medusa" and draft_lm is None and self.config.get("draft_model") in (None, "", "none", "NONE")
+        self.draft_lm = draft_lm if (draft_lm is not None or no_draft) else create_hip_lm(self.config["draft_model"])
         for who, lm in (("base", self.base_lm), ("draft", self.draft_lm)):
+            if lm is None and who == "draft":
+                continue                         # Medusa-lite drafts from the target itself (generate() only)
             if not isinstance(lm, HipLM):
                 raise TypeError(f"{who}_lm must be a HipLM (got {type(lm).__name__}): the step loop drives the "
                                 "models through the C-ABI engine, not through generate_tokens")
-        if self.base_lm.vocab_size != self.draft_lm.vocab_size:
+        if self.draft_lm is not None and self.base_lm.vocab_size != self.draft_lm.vocab_size:
             raise ValueError(f"draft/base vocabularies differ: {self.draft_lm.vocab_size} vs {self.base_lm.vocab_size}")
         self.speculative_enabled = True
         self.policy = create_policy(policy, **(policy_params or {}))
@@ -139,14 +151,14 @@ class SpeculativePipeline:
         return cfg
 
     # ------------------------------------------------------------------ runtime pieces
-    def _runtime(self, batch: int, need_len: int, k: int, emit_mode: int):
+    def _runtime(self, batch: int, need_len: int, k: int, emit_mode: int, self_draft: bool = False):
         """Engine instances (own KV caches over the shared weights) + the step loop object."""
-        key = (batch, emit_mode)
+        key = (batch, emit_mode, self_draft)
         rt = self._runtimes.get(key)
         if rt is None or rt["l_max"] < need_len:
             l_max = (max(need_len, 256) + 63) // 64 * 64
             rt = {"l_max": l_max, "target": self.base_lm.new_engine(batch, l_max),
-                  "draft": self.draft_lm.new_engine(batch, l_max), "loops": {}}
+                  "draft": None if self_draft else self.draft_lm.new_engine(batch, l_max), "loops": {}}
             self._runtimes[key] = rt
         loop = rt["loops"].get(k)
         if loop is None:
@@ -167,7 +179,8 @@ class SpeculativePipeline:
         toks = torch.tensor([seq[:-1]], dtype=torch.int32, device="cuda")
         zero = torch.zeros(1, dtype=torch.int32, device="cuda")
         rt["target"].forward(toks, zero, 0, skip_head=True, row0=b)
-        rt["draft"].forward(toks, zero, 0, skip_head=True, row0=b)
+        if rt["draft"] is not None:
+            rt["draft"].forward(toks, zero, 0, skip_head=True, row0=b)
 
     def _prefill(self, rt, rows: List[_Row]) -> None:
         lens = {len(r.seq) for r in rows}
@@ -175,7 +188,8 @@ class SpeculativePipeline:
             toks = torch.tensor([r.seq[:-1] for r in rows], dtype=torch.int32, device="cuda")
             zero = torch.zeros(len(rows), dtype=torch.int32, device="cuda")
             rt["target"].forward(toks, zero, 0, skip_head=True)
-            rt["draft"].forward(toks, zero, 0, skip_head=True)
+            if rt["draft"] is not None:
+                rt["draft"].forward(toks, zero, 0, skip_head=True)
         else:
             for b, r in enumerate(rows):
                 self._prefill_row(rt, b, r.seq)
@@ -253,15 +267,16 @@ class SpeculativePipeline:
 
     # ------------------------------------------------------------------ the loop
     def start_session(self, prompts: List[List[int]], max_tokens: int, emit_mode: int,
-                      sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None) -> "DecodeSession":
+                      sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None,
+                      self_draft: bool = False) -> "DecodeSession":
         """Prefill + device state for a batch of rows; `advance()` then runs one step at a time
         (generate / generate_batch drive it to completion, bench.py times exact step counts)."""
-        return DecodeSession(self, prompts, max_tokens, emit_mode, sampling, step_limit)
+        return DecodeSession(self, prompts, max_tokens, emit_mode, sampling, step_limit, self_draft)
 
     def _decode(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int,
-                sampling: Optional[Dict[str, Any]] = None):
+                sampling: Optional[Dict[str, Any]] = None, self_draft: bool = False):
         t_start = time.time()
-        sess = self.start_session(prompts, max_tokens, emit_mode, sampling, step_limit)
+        sess = self.start_session(prompts, max_tokens, emit_mode, sampling, step_limit, self_draft)
         while sess.any_active():    # every row stops after `step_limit` steps of its own
             if not sess.advance():
                 break
@@ -301,7 +316,10 @@ class SpeculativePipeline:
                 "global torch generator (pipeline.py:1019-1081); that is not restated. Use generate_batch(do_sample=True) "
                 "(sampled bonus token, reproducible) or do_sample=False")
         ids = self._encode(prompt)
-        rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens)
+        # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
+        # drafts with the draft model
+        rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
+                                self_draft=self.config.get("draft_mode") == "medusa")
         r = rows[0]
         total_ms = (time.time() - t_begin) * 1e3
         self.metrics = {"total_proposed": r.proposed, "total_accepted": r.accepted, "total_steps": st["steps"],
@@ -330,6 +348,8 @@ class SpeculativePipeline:
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
         sampling = self._sampling_config(do_sample, temperature, kwargs)
+        if self.draft_lm is None:
+            raise ValueError("generate_batch drafts with the draft model (the reference ignores draft_mode there): pass draft_lm / draft_model")
         ids = [self._encode(p) for p in prompts]
         rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling)
         total_ms = st["total_ms"]
@@ -368,7 +388,7 @@ class SpeculativePipeline:
             "cuda_mem_peak_mb": float(torch.cuda.max_memory_allocated() / 1024 / 1024),
             "policy": self.policy.get_info(), "controller": self.controller.get_info(),
             "impl": "hip", "device": self.device, "dtype": "bfloat16", "amp_enabled": False,
-            "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name,
+            "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name if self.draft_lm is not None else "none (medusa heads tied to the base lm_head)",
             "draft_mode": self.config.get("draft_mode", "vanilla"),
         }
 
@@ -387,8 +407,9 @@ class DecodeSession:
     sampled mode keep the launch -> wait -> rules order (the next launch depends on the host there)."""
 
     def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int,
-                 sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None):
+                 sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None, self_draft: bool = False):
         self.pipe, self.max_tokens, self.emit_mode = pipe, max_tokens, emit_mode
+        self.self_draft = self_draft
         self.sampling = sampling
         self.step_limit = step_limit
         if sampling is not None and emit_mode != HipSpecDec.EMIT_BONUS:
@@ -402,9 +423,10 @@ class DecodeSession:
         k_max = getattr(ctl, "max_k", None) or getattr(ctl, "k", 4)
         self.need = max(len(r.seq) for r in self.rows) + max_tokens + 2 * int(k_max) + 8
         self.k = int(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
-        self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode)
+        self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode, self.self_draft)
         # positions a row may use: the cache rows and both models' position tables
-        self.pos_limit = min(self.rt["l_max"], pipe.base_lm.config.max_pos, pipe.draft_lm.config.max_pos)
+        self.pos_limit = min(self.rt["l_max"], pipe.base_lm.config.max_pos,
+                             pipe.draft_lm.config.max_pos if not self_draft else pipe.base_lm.config.max_pos)
         for r in self.rows:
             if len(r.seq) + 2 * self.k + 4 > self.pos_limit:
                 raise ValueError(f"prompt of {len(r.seq)} tokens leaves no room for a step within {self.pos_limit} positions")
@@ -499,7 +521,7 @@ class DecodeSession:
                 self.loop.sync()
                 self._repair_rows()
                 self.k = k_new
-                self.rt, self.loop = pipe._runtime(len(rows), self.need, self.k, self.emit_mode)
+                self.rt, self.loop = pipe._runtime(len(rows), self.need, self.k, self.emit_mode, self.self_draft)
                 self.loop.join_current_stream()
                 for b, r in enumerate(rows):
                     pipe._set_row(self.loop, b, r)

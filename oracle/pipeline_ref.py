@@ -152,9 +152,14 @@ class OraclePipeline:
     `cpu_baseline` cost model; `reprefill=False` keeps per-model KV caches and gives the
     same tokens faster (used by the parity tests)."""
 
-    def __init__(self, base: OracleLM, draft: OracleLM, k: int = 4, eos_token_id: Optional[int] = None,
-                 reprefill: bool = False):
+    def __init__(self, base: OracleLM, draft: Optional[OracleLM], k: int = 4, eos_token_id: Optional[int] = None,
+                 reprefill: bool = False, draft_mode: str = "vanilla"):
+        """draft_mode "medusa_tied": the reference's MedusaDraftor (src/specdec/modes/medusa.py:71-186) with
+        head_init tie/copy under greedy decoding — every head is the base lm_head and head 0 is evaluated on the
+        same last hidden state for each of the K proposals, so the draft is K copies of the base model's own
+        next token (no draft model)."""
         self.base, self.draft, self.k = base, draft, int(k)
+        self.draft_mode = draft_mode
         self.eos = eos_token_id
         self.reprefill = reprefill
         self.vocab = base.cfg.vocab
@@ -165,8 +170,12 @@ class OraclePipeline:
         tokens t_0..t_K conditioned on seq + draft[:i]."""
         k = self.k
         ids = torch.tensor([seq], dtype=torch.int64)
-        d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill)
-        draft = d_ids[0].tolist()
+        if self.draft_mode == "medusa_tied":
+            t0, _ = self.base.generate_tokens(ids, 1, reprefill=self.reprefill)
+            draft = [int(t0[0, 0])] * k
+        else:
+            d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill)
+            draft = d_ids[0].tolist()
         if self.reprefill:
             # reference-faithful cost: the base model generates K tokens autoregressively
             # from the same prefix (speculative_scheduler.py:192-199), + the extra forward

@@ -240,3 +240,31 @@ def test_position_limit_stops_rows_without_faults():
         assert g == want[0].tolist()
     with pytest.raises(ValueError, match="no room"):
         pipe.generate_batch([list(range(4, 94))], max_tokens=4, do_sample=False)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_medusa_lite_tied_heads_generate(k):
+    """draft_mode='medusa' (generate() only, as in the reference): heads tied to the lm_head, head 0 on the same
+    hidden state for all K proposals = K copies of the target's next token (modes/medusa.py). The first proposal
+    is always accepted; tokens, counters and steps equal the oracle's restatement, and the text equals plain
+    greedy decoding of the target."""
+    from src.specdec import HipLM, SpeculativePipeline
+
+    drf, tgt = tiny_pair()
+    prompt = synthetic_prompts(1, 10, tgt.config.vocab)[0].tolist()
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt.to("cuda")), draft_model="none", draft_mode="medusa", controller="fixed",
+                               controller_params={"k": k}, seed=1234)
+    got = pipe.generate(prompt, max_tokens=14, do_sample=False)
+    lm = OracleLM(tgt, "bf16")
+    want = OraclePipeline(lm, None, k=k, eos_token_id=tgt.config.eos_token_id, draft_mode="medusa_tied").generate(prompt, 14)
+    assert got["generated_tokens"] == want["generated_tokens"]
+    assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
+    assert got["accepted"] >= got["steps"] and got["draft_mode"] == "medusa"
+    greedy, _ = lm.generate_tokens(torch.tensor([prompt]), 14)
+    assert got["generated_tokens"] == greedy[0].tolist()
+    with pytest.raises(ValueError, match="draft model"):
+        pipe.generate_batch([prompt], max_tokens=4, do_sample=False)
+    from src.specdec import SpeculativePipeline as SP
+
+    with pytest.raises(NotImplementedError, match="eagle"):
+        SP(base_lm=HipLM(tgt.to("cuda")), draft_lm=HipLM(drf.to("cuda")), draft_mode="eagle")
