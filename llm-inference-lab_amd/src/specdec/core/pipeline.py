@@ -381,6 +381,63 @@ class SpeculativePipeline:
             })
         return out
 
+    def generate_many(self, prompts: Sequence[PromptLike], max_tokens: Optional[int] = None, batch_size: int = 8,
+                      temperature: Optional[float] = None, do_sample: Optional[bool] = None, **kwargs) -> List[Dict[str, Any]]:
+        """Continuous batching over a list of prompts: `batch_size` rows decode together (generate_batch
+        semantics per row) and a finished row's slot is handed to the next waiting prompt at once, instead of
+        the reference harness' fixed batches that idle until their slowest row ends
+        (comprehensive_k_sweep.py:444-535). Rows are independent, so every result equals the prompt's own
+        generate_batch([prompt]) run. Results come back in prompt order."""
+        if not prompts:
+            return []
+        max_tokens = max_tokens or self.config["max_new_tokens"]
+        temperature = temperature or self.config["temperature"]
+        do_sample = do_sample if do_sample is not None else self.config["do_sample"]
+        sampling = self._sampling_config(do_sample, temperature, kwargs)
+        if self.draft_lm is None:
+            raise ValueError("generate_many drafts with the draft model: pass draft_lm / draft_model")
+        ids = [self._encode(p) for p in prompts]
+        n_slots = max(1, min(int(batch_size), len(ids)))
+        order = sorted(range(len(ids)), key=lambda i: -len(ids[i]))   # the longest prompts size the session
+        first = order[:n_slots]
+        waiting = [i for i in range(len(ids)) if i not in set(first)]
+        t_start = time.time()
+        sess = DecodeSession(self, [ids[i] for i in first], max_tokens, HipSpecDec.EMIT_BONUS, sampling, max_tokens)
+        owner: List[Optional[int]] = list(first)
+        done: Dict[int, Any] = {}
+        while len(done) < len(ids):
+            if sess.any_active():
+                if not sess.advance():
+                    break
+            for b, r in enumerate(sess.rows):
+                if owner[b] is not None and not r.active:
+                    done[owner[b]] = (r, (time.time() - t_start) * 1e3)
+                    owner[b] = None
+                    if waiting:
+                        nxt = waiting.pop(0)
+                        sess.admit(b, ids[nxt])
+                        owner[b] = nxt
+            if not sess.any_active() and not waiting and all(o is None for o in owner):
+                break
+        sess.finish()
+        torch.cuda.synchronize()
+        total_ms = (time.time() - t_start) * 1e3
+        tot_tok = sum(len(r.generated) for r, _ in done.values())
+        out = []
+        for i, p in enumerate(prompts):
+            r, t_ms = done[i]
+            n = len(r.generated)
+            text = self.base_lm.decode(r.generated) if r.generated else ""
+            out.append({"prompt": p, "text": text, "generated_text": text, "generated_tokens": list(r.generated), "num_generated": n,
+                        "batch_index": i, "batch_size": n_slots, "latency_ms": t_ms, "total_time_ms": total_ms,
+                        "tokens_per_sec": n / (t_ms / 1e3) if t_ms > 0 else 0.0,
+                        "throughput_tokens_per_sec": tot_tok / (total_ms / 1e3) if total_ms > 0 else 0.0,
+                        "acceptance_rate": r.accepted / max(r.proposed, 1), "proposed": r.proposed, "accepted": r.accepted,
+                        "steps": r.steps, "sequence": list(r.seq), "kv_append_enabled": True, "kv_append_backend": "hip",
+                        "batch_metrics": {"total_steps": sess.stats["steps"], "device_steps": sess.step, "resyncs": sess.stats["resyncs"],
+                                          "void_row_steps": sess.stats["void_row_steps"], "k": sess.k}})
+        return out
+
     def _sysinfo(self) -> Dict[str, Any]:
         return {
             "mem_rss_mb": psutil.Process().memory_info().rss / 1024 / 1024,
@@ -486,6 +543,9 @@ class DecodeSession:
 
     def _launch(self) -> None:
         self._repair_rows()
+        if getattr(self, "_resample_state", False):
+            self._resample_state = False
+            self._apply_sampling()
         self.loop.step(use_graph=True)
         self._inflight = True
         self._void = set()
@@ -573,6 +633,22 @@ class DecodeSession:
                 self._void.add(b)
         stats["steps"] = max(r.steps for r in rows)
         return True
+
+    def admit(self, b: int, prompt: List[int]) -> None:
+        """Continuous batching: put a new sequence into the slot of a finished row. Its caches are prefilled
+        and its device state set at the next launch point; the other rows keep stepping meanwhile."""
+        if self.rows[b].active:
+            raise ValueError(f"row {b} is still decoding")
+        if not prompt:
+            raise ValueError("empty prompt")
+        if len(prompt) + self.max_tokens + 2 * self.k + 8 > self.rt["l_max"] or len(prompt) + 2 * self.k + 4 > self.pos_limit:
+            raise ValueError(f"prompt of {len(prompt)} tokens does not fit this session (l_max {self.rt['l_max']}, positions {self.pos_limit})")
+        self.rows[b] = _Row(list(prompt))
+        self._flagged[b] = "resync"
+        if self._inflight:
+            self._void.add(b)
+        if self.sampling is not None:
+            self._resample_state = True   # draw counters restart for the new row at the next launch point
 
     def finish(self) -> None:
         """Drain a step launched ahead of a run that ended, and leave the device rows consistent."""
