@@ -62,9 +62,11 @@ def parse():
     ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: both models stream an OCP e4m3 copy of their Linear weights (per-row scales, bf16 activations and "
                          "MFMA); not the headline configuration (BASELINE config 2 is bf16), CPU parity leg uses the dequantised weights")
-    ap.add_argument("--draft-mode", choices=["vanilla", "medusa"], default="vanilla",
+    ap.add_argument("--draft-mode", choices=["vanilla", "medusa", "medusa-heads"], default="vanilla",
                     help="medusa: BASELINE config 5's draft — Medusa-lite heads tied to the lm_head (the reference draftor's "
-                         "semantics: K copies of the target's next token), single-prompt generate() loop, no draft model")
+                         "semantics: K copies of the target's next token), single-prompt generate() loop, no draft model; "
+                         "medusa-heads: K persistent heads over the target's last hidden state (not in the reference; synthetic heads, "
+                         "--flip of their rows wrong), generate_batch loop")
     ap.add_argument("--do-sample", action="store_true",
                     help="sampled bonus token (T=0.7, top_k=50, top_p=0.9: the reference's default sampler) instead of greedy; "
                          "not the headline configuration (SPECDEC_DETERMINISTIC is greedy), no CPU parity leg")
@@ -164,9 +166,15 @@ def main():
     drf, tgt, source = build_models(args, device)
     wd = args.weight_dtype
     medusa = args.draft_mode == "medusa"
-    pipe = SpeculativePipeline(base_lm=HipLM(tgt, weight_dtype=wd), draft_lm=HipLM(drf, weight_dtype=wd), controller="fixed",
-                               controller_params={"k": args.k}, seed=1234, draft_mode=args.draft_mode)
-    if medusa:
+    heads = None
+    if args.draft_mode == "medusa-heads":
+        from specdec_hip import weights as W
+
+        heads = W.synthetic_medusa_heads(tgt, args.k, flip_fraction=args.flip)
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt, weight_dtype=wd), draft_lm=None if heads is not None else HipLM(drf, weight_dtype=wd),
+                               draft_model="none", controller="fixed", controller_params={"k": args.k}, seed=1234,
+                               draft_mode="medusa" if heads is not None else args.draft_mode, medusa_heads=heads)
+    if medusa or heads is not None:
         args.cpu_baseline_steps = 0
     K, B = args.k, args.batch
     prompts = prompts_for(rank, B, tgt.config.vocab)
@@ -176,7 +184,7 @@ def main():
         args.cpu_baseline_steps = 0
     sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1,
                               emit_mode=HipSpecDec.EMIT_DRAFT if medusa else HipSpecDec.EMIT_BONUS,
-                              sampling=sampling, self_draft=medusa)
+                              sampling=sampling, self_draft=medusa or heads is not None)
 
     def barrier():
         if dist is not None:
@@ -215,6 +223,8 @@ def main():
     value = job.tokens_per_s()
     ms_per_step = t_max / args.steps * 1e3
     bytes_step = (2 * tgt.matmul_bytes()) if medusa else (K * drf.matmul_bytes() + tgt.matmul_bytes())
+    if heads is not None:
+        bytes_step = tgt.matmul_bytes() + K * tgt.config.vocab * tgt.config.d_model * 2
     if wd == "fp8":
         bytes_step //= 2      # one byte per weight (+ 4 bytes per output row of scales: < 0.1 %)
     out = {
@@ -222,7 +232,7 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
-        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{', Medusa-lite tied heads (self-draft), generate() loop' if medusa else ''}, "
+        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{', Medusa-lite tied heads (self-draft), generate() loop' if medusa else ''}{', persistent Medusa heads (synthetic)' if heads is not None else ''}, "
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},

@@ -208,6 +208,11 @@ typedef struct sd_model_config {
  * w[r][k] / scales[r]. sd_pack_weights applies exactly this before re-ordering. Asynchronous on `stream`. */
 int sd_quantize_fp8_rows(const void* w_bf16, int N, int K, void* q_fp8, float* scales, void* stream);
 
+/* One vocabulary-sized output matrix [vocab][d_model] (bf16, row-major) outside a model — a Medusa head — in the
+ * engine's tile-stream order, bf16 or fp8 e4m3 with row scales (the lm_head's layout and quantiser). */
+size_t sd_packed_head_bytes(int vocab, int d_model, int weight_dtype);
+int sd_pack_head(const void* w_bf16, int vocab, int d_model, int weight_dtype, void* dst, size_t dst_bytes, void* stream);
+
 /* Weight pre-packing: the engine's private copy of all Linear weights in the order the
  * streaming GEMV consumes them (csrc/pack.hip), so that every wave reads one contiguous
  * region of HBM. sd_packed_bytes gives the buffer size (device memory, 256-byte aligned);
@@ -294,6 +299,14 @@ int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_tok, int last
 int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperature, int top_k, float top_p,
                             uint64_t seed, void* logits_buf, size_t logits_bytes,
                             uint32_t* draw_counters, const int32_t* stream_ids);
+
+/* Persistent multi-head (Medusa) drafting for a loop created with draft = NULL: K heads, each a
+ * vocabulary-sized matrix [V][d_model] packed by sd_pack_head in `weight_dtype`. After the accept scan of a step
+ * the heads read the target's final-norm input row of the position that produced the last emitted token and
+ * propose d_{i+1} = argmax head_i(norm(h)) for the NEXT step: one lm_head-shaped GEMV per head, no draft forwards.
+ * (Not in the reference: its Medusa mode re-creates random heads per call, pipeline.py:689-705)
+ * Requires B <= 9 and B*(K+1) within one verify pass. Drops the captured graph. */
+int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* const* packed_heads, int weight_dtype);
 
 /* Enqueue ONE draft-then-verify step for all rows: K draft forwards (the first over
  * (prev,last), the rest over one token), one verify forward over (last,d_1..d_K),

@@ -542,6 +542,10 @@ struct sd_specdec {
   void* logits = nullptr;          // [B][K+1][V] bf16
   uint32_t* draw = nullptr;        // [B]
   const int32_t* stream_id = nullptr;
+  // persistent Medusa heads (sd_specdec_set_medusa): K packed [V][d] matrices + their fp32 row scales (fp8)
+  std::vector<const void*> heads;
+  std::vector<const float*> head_scales;
+  int32_t* head_rows = nullptr;    // [B] device: row of the target's residual stream each head reads
 };
 
 namespace sd {
@@ -562,10 +566,48 @@ __global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t
   if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
 }
 
+// draft tokens of the NEXT step from the heads: d_{i+1} = argmax head_i(final_norm(h)), h = the residual row of the
+// position that produced the last emitted token. One lm_head-shaped GEMV + finalize per head.
+static int enqueue_medusa_heads(sd_specdec* s, hipStream_t st) {
+  sd_model* m = s->target;
+  const sd_model_config& c = m->cfg;
+  const int B = s->B, K = s->K;
+  if (int rc = launch_medusa_rows(s->st, s->head_rows, st)) return rc;
+  for (int i = 0; i < K; ++i) {
+    GemvArgs h{};
+    h.packed = 1;
+    h.w8 = s->head_scales.empty() ? 0 : 1;
+    h.w_scale = s->head_scales.empty() ? nullptr : s->head_scales[i];
+    h.W = s->heads[i];
+    h.N = c.vocab;
+    h.K = c.d_model;
+    h.n_pairs = (c.vocab + 1) / 2;
+    h.x = m->x;
+    h.x_stride = c.d_model;
+    h.x_row = s->head_rows;
+    h.T = B;
+    h.M = 1;
+    h.prologue = (c.arch == SD_ARCH_LLAMA) ? PRO_RMSNORM : PRO_LAYERNORM;
+    h.norm_w = c.final_norm_w;
+    h.norm_b = c.final_norm_b;
+    h.norm_eps = c.norm_eps;
+    h.out = nullptr;
+    h.out_dtype = SD_BF16;
+    h.part_val = m->part_val;
+    h.part_idx = m->part_idx;
+    int ppw = 1;
+    const int grid = gemv_grid(h, &ppw);
+    if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
+    // token of head i of row b -> verify_tok[b][i+1]
+    if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, B, grid, 1, K + 1, s->st.verify_tok + i + 1, st)) return rc;
+  }
+  return launch_medusa_commit(s->st, st);
+}
+
 static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   const int B = s->B, K = s->K;
   const bool two = (st_d != st_t) && s->draft;
-  if (!s->draft) {
+  if (!s->draft && s->heads.empty()) {
     // self-draft (Medusa-lite, tied heads): the target's own next token, K times
     if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, 1, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_t))
       return rc;
@@ -603,6 +645,9 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   hipLaunchKernelGGL(pack_record_kernel, dim3(B), dim3(kWave), 0, st_t, s->st, s->dev_record, s->rec);
   SD_LAUNCH_CHECK();
   SD_HIP_CHECK(hipMemcpyAsync(s->host_record, s->dev_record, sizeof(int32_t) * B * s->rec, hipMemcpyDeviceToHost, st_t));
+  // persistent Medusa heads: the proposals of the next step, after the record of this one has left
+  if (!s->heads.empty())
+    if (int rc = enqueue_medusa_heads(s, st_t)) return rc;
   return 0;
 }
 
@@ -670,6 +715,7 @@ extern "C" int sd_specdec_destroy(sd_specdec* s) {
   if (s->host_record) (void)hipHostFree(s->host_record);
   if (s->host_stage) (void)hipHostFree(s->host_stage);
   if (s->dev_block) (void)hipFree(s->dev_block);
+  if (s->head_rows) (void)hipFree(s->head_rows);
   delete s;
   return 0;
 }
@@ -725,6 +771,37 @@ extern "C" int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperat
   s->logits = logits_buf;
   s->draw = draw_counters;
   s->stream_id = stream_ids;
+  return 0;
+}
+
+extern "C" int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* const* packed_heads, int weight_dtype) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_set_medusa: NULL");
+  SD_REQUIRE(!s->draft, "specdec_set_medusa: the loop was created with a draft model (pass draft = NULL)");
+  SD_REQUIRE(n_heads == s->K && packed_heads, "specdec_set_medusa: need K = %d heads, got %d", s->K, n_heads);
+  SD_REQUIRE(weight_dtype == SD_BF16 || weight_dtype == SD_FP8_E4M3, "specdec_set_medusa: weight_dtype %d", weight_dtype);
+  const sd_model_config& c = s->target->cfg;
+  SD_REQUIRE(s->B <= gemv_max_tokens(c.d_model), "specdec_set_medusa: batch %d exceeds one GEMV pass (%d rows)", s->B, gemv_max_tokens(c.d_model));
+  SD_REQUIRE(s->B * (s->K + 1) <= s->target->max_t, "specdec_set_medusa: the verify pass must be a single pass (B*(K+1) = %d > %d)",
+             s->B * (s->K + 1), s->target->max_t);
+  if (s->exec) {
+    (void)hipGraphExecDestroy(s->exec);
+    (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+  }
+  s->heads.clear();
+  s->head_scales.clear();
+  for (int i = 0; i < n_heads; ++i) {
+    SD_REQUIRE(packed_heads[i], "specdec_set_medusa: head %d is NULL", i);
+    s->heads.push_back(packed_heads[i]);
+    if (weight_dtype == SD_FP8_E4M3) {
+      const size_t off = packed_any_matrix_bytes((c.vocab + 1) / 2, c.d_model, SD_FP8_E4M3) -
+                         ((static_cast<size_t>((c.vocab + 1) / 2) * 2 * 4 + 255) & ~static_cast<size_t>(255));
+      s->head_scales.push_back(reinterpret_cast<const float*>(static_cast<const char*>(packed_heads[i]) + off));
+    }
+  }
+  if (!s->head_rows) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->head_rows), sizeof(int32_t) * s->B));
   return 0;
 }
 

@@ -500,6 +500,7 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   SD_REQUIRE(a.T >= 1 && a.T <= kSkinnyMaxT, "gemm_skinny: T=%d out of range 1..%d", a.T, kSkinnyMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemm_skinny: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
   SD_REQUIRE(a.n_pairs > 0, "gemm_skinny: no rows");
+  SD_REQUIRE(!a.x_row, "gemm_skinny: gathered activation rows are a gemv.hip (<= 9 tokens) feature");
   SD_REQUIRE(!a.w8 || (a.packed && a.w_scale), "gemm_skinny: fp8 weights need the packed layout and row scales");
   const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
   a.ppw = q.ppw;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
   const int lane = tid & 63, wave = tid >> 6;
 
   for (int t = 0; t < T; ++t) {
-    const uint4* src = reinterpret_cast<const uint4*>(xin + static_cast<size_t>(t) * a.x_stride);
+    const uint4* src = reinterpret_cast<const uint4*>(xin + static_cast<size_t>(a.x_row ? a.x_row[t] : t) * a.x_stride);
     uint4* dst = reinterpret_cast<uint4*>(xs + static_cast<size_t>(t) * KP);
     float s1 = 0.f, s2 = 0.f;
     for (int v = tid; v < nvec; v += kGemvThreads) {
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int tt = (t < T) ? t : T - 1;
-      xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(tt) * a.x_stride + cidx * 8);
+      const int xrow_i = a.x_row ? a.x_row[tt] : tt;   // gathered rows (Medusa heads read the accepted position's hidden row)
+      xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(xrow_i) * a.x_stride + cidx * 8);
     }
     if (a.prologue != PRO_NONE) {  // kernel-uniform
       nw4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + cidx * 8);

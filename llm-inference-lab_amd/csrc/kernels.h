@@ -32,6 +32,7 @@ struct GemvArgs {
   // activations in: bf16 [T][x_stride]
   const void* x;
   int x_stride;
+  const int32_t* x_row;  // nullable, device [T]: token t reads row x_row[t] of x instead of row t (gemv.hip only)
   int T;             // tokens in this pass
   int M;             // tokens per batch row (t = b*M + m)
   // fused normalisation of x
@@ -65,6 +66,8 @@ struct GemvGeom {
 };
 GemvGeom gemv_geometry(int n_pairs, int K);
 size_t packed_matrix_bytes(int n_pairs, int K);
+size_t packed_any_matrix_bytes(int n_pairs, int K, int weight_dtype);   // bf16 or fp8 (+ scales)
+int pack_one_matrix(const void* w_bf16, int N, int K, int n_pairs, int epi, int head_dim, int weight_dtype, void* dst, hipStream_t st);
 size_t packed_scale_offset(const sd_model_config& c, int index);  // fp8: row scales follow the packed bytes of a matrix
 size_t packed_offset(const sd_model_config& c, int index);  // index: 4*layer + {0 qkv,1 out,2 up,3 down}; 4*n_layers = lm_head
 int gemv_grid(const GemvArgs& a, int* ppw_out);

@@ -103,6 +103,31 @@ __global__ void medusa_fill_kernel(SpecState s) {
   s.next_tok[b] = d;
 }
 
+// Persistent Medusa heads: row of the target's residual stream that predicted the last emitted token
+// (position accept_len of the verify pass), and the hand-over of the heads' tokens to the next step.
+__global__ void medusa_rows_kernel(SpecState s, int32_t* row_idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < s.B) row_idx[b] = b * (s.K + 1) + s.accept_len[b];
+}
+
+__global__ void medusa_commit_kernel(SpecState s) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.B) return;
+  for (int i = 0; i < s.K; ++i) s.draft_tok[b * s.K + i] = s.verify_tok[b * (s.K + 1) + i + 1];
+}
+
+int launch_medusa_rows(const SpecState& s, int32_t* row_idx, hipStream_t st) {
+  hipLaunchKernelGGL(medusa_rows_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, s, row_idx);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_medusa_commit(const SpecState& s, hipStream_t st) {
+  hipLaunchKernelGGL(medusa_commit_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, s);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_medusa_fill(const SpecState& s, hipStream_t st) {
   hipLaunchKernelGGL(medusa_fill_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, s);
   SD_LAUNCH_CHECK();

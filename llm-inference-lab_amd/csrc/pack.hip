@@ -213,9 +213,43 @@ size_t packed_scale_offset(const sd_model_config& c, int index) {
   return packed_fp8_weight_bytes(mats[index].n_pairs, mats[index].K);
 }
 
+size_t packed_any_matrix_bytes(int n_pairs, int K, int weight_dtype) {
+  return weight_dtype == SD_FP8_E4M3 ? packed_fp8_matrix_bytes(n_pairs, K) : packed_matrix_bytes(n_pairs, K);
+}
+
+int pack_one_matrix(const void* w_bf16, int N, int K, int n_pairs, int epi, int head_dim, int weight_dtype, void* dst, hipStream_t st) {
+  SD_REQUIRE(w_bf16 && dst, "pack: NULL matrix");
+  SD_REQUIRE(K % 8 == 0, "pack: K=%d must be a multiple of 8", K);
+  const GemvGeom q = gemv_geometry(n_pairs, K);
+  PackJob j{static_cast<const uint16_t*>(w_bf16), static_cast<uint16_t*>(dst), N, K, n_pairs, epi, head_dim, q.ppw, q.tile_pairs};
+  if (weight_dtype == SD_FP8_E4M3) {
+    float* scale = reinterpret_cast<float*>(static_cast<char*>(dst) + packed_fp8_weight_bytes(n_pairs, K));
+    hipLaunchKernelGGL(row_scale_kernel, dim3(N), dim3(kWave), 0, st, static_cast<const uint16_t*>(w_bf16), N, K, scale);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3(2048), dim3(256), 0, st, j, scale);
+  } else {
+    hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, st, j);
+  }
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace sd
 
 using namespace sd;
+
+// A vocabulary-sized output matrix [V][d] outside a model (Medusa heads): same layout and quantiser as the lm_head.
+extern "C" size_t sd_packed_head_bytes(int vocab, int d_model, int weight_dtype) {
+  return packed_any_matrix_bytes((vocab + 1) / 2, d_model, weight_dtype);
+}
+
+extern "C" int sd_pack_head(const void* w_bf16, int vocab, int d_model, int weight_dtype, void* dst, size_t dst_bytes, void* stream) {
+  clear_error();
+  SD_REQUIRE(weight_dtype == SD_BF16 || weight_dtype == SD_FP8_E4M3, "pack_head: weight_dtype %d", weight_dtype);
+  SD_REQUIRE(dst_bytes >= sd_packed_head_bytes(vocab, d_model, weight_dtype), "pack_head: destination too small");
+  SD_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 255) == 0, "pack_head: destination must be 256-byte aligned");
+  return pack_one_matrix(w_bf16, vocab, d_model, (vocab + 1) / 2, EPI_ARGMAX, 0, weight_dtype, dst, static_cast<hipStream_t>(stream));
+}
 
 extern "C" size_t sd_packed_bytes(const sd_model_config* cfg) {
   if (!cfg || !cfg->layers) return 0;

@@ -222,6 +222,25 @@ class HipSpecDec:
             _abi.check(self.lib.sd_specdec_set_row(self.handle, b, int(seq_len), int(prev_tok), int(last_tok),
                                                    1 if active else 0, self.stream_t.cuda_stream), "sd_specdec_set_row")
 
+    def set_medusa(self, heads: torch.Tensor, weight_dtype: str = "bf16"):
+        """Persistent Medusa heads for a loop created with draft=None (sd_specdec_set_medusa). heads: bf16 [K][V][d];
+        each is packed (and quantised for fp8) once, like the lm_head."""
+        K, V, d = heads.shape
+        if K != self.K or heads.dtype != torch.bfloat16 or heads.device != self.device:
+            raise ValueError(f"medusa heads must be bf16 [{self.K}][V][d] on {self.device}")
+        wd = _abi.SD_FP8_E4M3 if weight_dtype == "fp8" else _abi.SD_BF16
+        nbytes = self.lib.sd_packed_head_bytes(V, d, wd)
+        self._heads_packed = []
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device)
+            for i in range(K):
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                _abi.check(self.lib.sd_pack_head(heads[i].contiguous().data_ptr(), V, d, wd, buf.data_ptr(), nbytes, st.cuda_stream), "sd_pack_head")
+                self._heads_packed.append(buf)
+            st.synchronize()
+            arr = (ctypes.c_void_p * K)(*[b.data_ptr() for b in self._heads_packed])
+            _abi.check(self.lib.sd_specdec_set_medusa(self.handle, K, arr, wd), "sd_specdec_set_medusa")
+
     def set_sampling(self, enable: bool, temperature: float = 1.0, top_k: Optional[int] = None,
                      top_p: Optional[float] = None, seed: int = 0, stream_ids: Optional[Sequence[int]] = None,
                      draw_counts: Optional[Sequence[int]] = None):

@@ -398,3 +398,40 @@ def synthetic_gpt2(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.bf
         meta={"synthetic": True, "seed": seed, "layer_gain": layer_gain, "flip_fraction": flip_fraction,
               "successor": (successor_mult, successor_add)},
     )
+
+
+# ------------------------------------------------------------------------------- Medusa heads
+@dataclass
+class MedusaHeads:
+    """K persistent vocabulary-sized heads over the target's last hidden state: head i proposes the token
+    i+1 positions after the last emitted one. weights: bf16 [K][V][d_model]."""
+    weights: torch.Tensor
+    meta: Dict[str, object] = field(default_factory=dict)
+
+    @property
+    def n_heads(self) -> int:
+        return int(self.weights.shape[0])
+
+
+def synthetic_medusa_heads(target: ModelWeights, n_heads: int, flip_fraction: float = 0.2, flip_seed: int = 7) -> MedusaHeads:
+    """Heads for a `synthetic_llama` target. The target's hidden state before the lm_head points at E_out[t]
+    where t is its next token, and its greedy walk is t -> succ(t); head i is therefore the output table with
+    its rows moved along the walk, head_i[succ^i(t)] = E_out[t], so that argmax head_i(h) = succ^i(t). For a
+    `flip_fraction` of the tokens (per head) the row goes to another token: those proposals are wrong, which
+    sets the acceptance rate by construction (as `synthetic_llama(..., flip_fraction)` does for a draft model)."""
+    mult, add = target.meta.get("successor", (7919, 1))
+    e_out = target.lm_head
+    V, d = e_out.shape
+    dev = e_out.device
+    tok = torch.arange(V, device=dev, dtype=torch.int64)
+    heads = torch.empty((n_heads, V, d), dtype=e_out.dtype, device=dev)
+    dest = tok.clone()
+    fg = torch.Generator(device="cpu").manual_seed(flip_seed)
+    for i in range(n_heads):
+        dest = (dest * mult + add) % V                       # succ^(i+1)(t) for every t
+        flip = (torch.rand(V, generator=fg) < flip_fraction).to(dev)
+        wrong = (dest * 31 + 17) % V
+        target_row = torch.where(flip, wrong, dest)
+        heads[i].zero_()
+        heads[i].index_copy_(0, target_row, e_out)           # collisions: the later source row wins (still one hot spot each)
+    return MedusaHeads(heads, meta={"synthetic": True, "flip_fraction": flip_fraction})

@@ -83,7 +83,7 @@ class SpeculativePipeline:
                  policy_params: Optional[Dict[str, Any]] = None, controller: str = "fixed",
                  controller_params: Optional[Dict[str, Any]] = None, draft_mode: str = "vanilla",
                  enable_optimization: bool = True, enable_profiling: bool = False,
-                 profile_dir: Optional[str] = None):
+                 profile_dir: Optional[str] = None, medusa_heads: Optional[Any] = None):
         self.logger = logging.getLogger(__name__)
         self.config = self._load_config(config_path)
         for key, val in (("base_model", base_model), ("draft_model", draft_model), ("max_draft", max_draft),
@@ -96,7 +96,14 @@ class SpeculativePipeline:
             # counterpart here: the product is the GPU path
             raise ValueError(f"implementation={impl!r} is not available in this build (use 'hip')")
         mode = self.config.get("draft_mode", "vanilla")
-        if mode == "medusa":
+        # persistent heads (specdec_hip.weights.MedusaHeads): not in the reference — K trained/tied heads evaluated
+        # in K GEMVs over the target's last hidden state replace the draft forwards
+        self.medusa_heads = medusa_heads
+        if medusa_heads is not None and mode != "medusa":
+            raise ValueError("medusa_heads needs draft_mode='medusa'")
+        if mode == "medusa" and medusa_heads is not None:
+            pass
+        elif mode == "medusa":
             # Medusa-lite as the reference's draftor defines it (modes/medusa.py): heads tied to / copied from the
             # lm_head, head 0 evaluated on the same last hidden state for all K proposals -> K copies of the
             # target's own next token. The pipeline's HF path re-creates RANDOM heads on every call
@@ -163,6 +170,10 @@ class SpeculativePipeline:
         loop = rt["loops"].get(k)
         if loop is None:
             loop = rt["loops"][k] = HipSpecDec(rt["draft"], rt["target"], batch, k, emit_mode)
+            if self_draft and self.medusa_heads is not None:
+                if self.medusa_heads.n_heads != k:
+                    raise ValueError(f"{self.medusa_heads.n_heads} medusa heads but K={k}")
+                loop.set_medusa(self.medusa_heads.weights, self.base_lm.weight_dtype)
         return rt, loop
 
     def _encode(self, prompt: PromptLike) -> List[int]:
@@ -348,10 +359,11 @@ class SpeculativePipeline:
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
         sampling = self._sampling_config(do_sample, temperature, kwargs)
-        if self.draft_lm is None:
+        heads = self.medusa_heads is not None    # persistent heads also serve generate_batch (opt-in, not in the reference)
+        if self.draft_lm is None and not heads:
             raise ValueError("generate_batch drafts with the draft model (the reference ignores draft_mode there): pass draft_lm / draft_model")
         ids = [self._encode(p) for p in prompts]
-        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling)
+        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling, self_draft=heads)
         total_ms = st["total_ms"]
         tot_prop = sum(r.proposed for r in rows)
         tot_acc = sum(r.accepted for r in rows)
@@ -496,7 +508,10 @@ class DecodeSession:
         self.step = 0
         from ..policies.controllers import FixedKController
 
+        # (persistent Medusa heads: a void step would replace the next proposals with ones derived from stale state —
+        # harmless for the tokens, but the counters would no longer be those of the in-order loop)
         self._early = (isinstance(ctl, FixedKController) and sampling is None
+                       and not (self_draft and pipe.medusa_heads is not None)
                        and os.environ.get("SPECDEC_EARLY_LAUNCH", "1") != "0")
         self._inflight = False
         self._flagged: Dict[int, str] = {}   # rows whose device state must be repaired before the next launch

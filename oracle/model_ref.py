@@ -167,11 +167,21 @@ class OracleLM:
             if lw.b_down is not None:
                 y = y + self._m(k0 + "bdown", lw.b_down)
             x = self._r(x + y)
+        self.last_hidden = x            # residual stream before the final norm [B][L][d] (Medusa heads read it)
         if not need_logits:
             return None, new_past
         xn = self._norm(x, "nf", W.final_norm_w, W.final_norm_b)
         logits = self._r(xn @ self._m("lm_head", W.lm_head).t())
         return logits, new_past
+
+    def head_tokens(self, hidden_row: torch.Tensor, heads: torch.Tensor) -> List[int]:
+        """argmax head_i(final_norm(h)) for every head: bf16-rounded logits as the lm_head's."""
+        xn = self._norm(hidden_row.view(1, 1, -1), "nf", self.w.final_norm_w, self.w.final_norm_b)
+        out = []
+        for i in range(heads.shape[0]):
+            key = f"medusa{i}"
+            out.append(int(self._r(xn @ self._m(key, heads[i]).t()).view(-1).argmax()))
+        return out
 
     # ---- greedy generation, the semantics of HFWrapper._generate_tokens_async -------
     def generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, reprefill: bool = False):

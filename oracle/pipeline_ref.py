@@ -153,23 +153,37 @@ class OraclePipeline:
     same tokens faster (used by the parity tests)."""
 
     def __init__(self, base: OracleLM, draft: Optional[OracleLM], k: int = 4, eos_token_id: Optional[int] = None,
-                 reprefill: bool = False, draft_mode: str = "vanilla"):
+                 reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None):
         """draft_mode "medusa_tied": the reference's MedusaDraftor (src/specdec/modes/medusa.py:71-186) with
         head_init tie/copy under greedy decoding — every head is the base lm_head and head 0 is evaluated on the
         same last hidden state for each of the K proposals, so the draft is K copies of the base model's own
         next token (no draft model)."""
         self.base, self.draft, self.k = base, draft, int(k)
         self.draft_mode = draft_mode
+        # "medusa_heads" (not in the reference, SURVEY §8 f4): persistent heads [K][V][d]; the proposals of a step
+        # are argmax head_i(final_norm(h)) with h = the base model's residual row at the position that produced the
+        # last emitted token in the PREVIOUS step's verify pass; a row's first step proposes zeros
+        self.medusa_heads = medusa_heads
+        self._next_draft: Dict[int, List[int]] = {}
         self.eos = eos_token_id
         self.reprefill = reprefill
         self.vocab = base.cfg.vocab
         self.trace: List[Dict] = []
 
-    def _propose_and_verify(self, seq: List[int]):
+    def _propose_and_verify(self, seq: List[int], row: int = 0):
         """draft K greedy tokens from seq (pipeline.py:2397-2462) and the target's greedy
         tokens t_0..t_K conditioned on seq + draft[:i]."""
         k = self.k
         ids = torch.tensor([seq], dtype=torch.int64)
+        if self.draft_mode == "medusa_heads":
+            draft = self._next_draft.get(row, [0] * k)
+            lg, _ = self.base.forward(torch.tensor([seq + draft], dtype=torch.int64))
+            self.last_logits = lg[0, len(seq) - 1:]
+            t = self.last_logits.argmax(-1).tolist()
+            a = longest_prefix(draft, t)
+            h = self.base.last_hidden[0, len(seq) - 1 + a]
+            self._next_draft[row] = self.base.head_tokens(h, self.medusa_heads)
+            return draft, t, a
         if self.draft_mode == "medusa_tied":
             t0, _ = self.base.generate_tokens(ids, 1, reprefill=self.reprefill)
             draft = [int(t0[0, 0])] * k
@@ -209,6 +223,7 @@ class OraclePipeline:
             raise ValueError("sampling needs the cached verify pass (reprefill=False)")
         rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
         self.trace = []
+        self._next_draft = {}
         t0 = time.time()
         step = 0
         while step < max_tokens and (max_steps is None or step < max_steps):   # :1984 bound is STEPS, not tokens
@@ -218,7 +233,7 @@ class OraclePipeline:
             for i, r in enumerate(rows):
                 if not r.active:
                     continue
-                draft, t, a = self._propose_and_verify(r.seq)
+                draft, t, a = self._propose_and_verify(r.seq, i)
                 before = len(r.seq)
                 bonus_at = None
                 if sampling is not None:
@@ -240,6 +255,7 @@ class OraclePipeline:
     def generate(self, prompt: Sequence[int], max_tokens: int) -> Dict:
         r = RowState(seq=[int(x) for x in prompt])
         self.trace = []
+        self._next_draft = {}
         t0 = time.time()
         step = 0
         while len(r.generated) < max_tokens and step < 2 * max_tokens:   # :984-986

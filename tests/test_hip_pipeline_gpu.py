@@ -295,3 +295,41 @@ def test_generate_many_continuous_batching():
     s1 = pipe.generate_many(prompts[:5], max_tokens=10, batch_size=2, do_sample=True, temperature=20.0, top_k=50, top_p=0.95, seed=7)
     s2 = pipe.generate_many(prompts[:5], max_tokens=10, batch_size=2, do_sample=True, temperature=20.0, top_k=50, top_p=0.95, seed=7)
     assert [r["generated_tokens"] for r in s1] == [r["generated_tokens"] for r in s2]
+
+
+@pytest.mark.parametrize("k,batch,wd", [(4, 1, "bf16"), (2, 3, "bf16"), (4, 2, "fp8")])
+def test_persistent_medusa_heads(k, batch, wd):
+    """K persistent heads over the target's last hidden state replace the draft forwards (not in the reference,
+    SURVEY §8 f4): tokens, proposed/accepted counters and steps equal the oracle restatement; the output is the
+    target's greedy continuation; with 20 % wrong head rows the acceptance is high but not total."""
+    from oracle import fp8_ref
+    from specdec_hip import weights as W
+    from src.specdec import HipLM, SpeculativePipeline
+
+    drf, tgt = tiny_pair()
+    heads = W.synthetic_medusa_heads(tgt, k, flip_fraction=0.2)
+    V = tgt.config.vocab
+    prompts = synthetic_prompts(batch, 9, V).tolist()
+    gh = W.MedusaHeads(heads.weights.cuda())
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt.to("cuda"), weight_dtype=wd), draft_model="none", draft_mode="medusa", medusa_heads=gh,
+                               controller="fixed", controller_params={"k": k}, seed=1234)
+    got = pipe.generate_batch(prompts, max_tokens=24, do_sample=False)
+    if wd == "fp8":
+        tq = fp8_ref.dequantized(tgt)
+        hq = torch.stack([fp8_ref.quantize_rows(h)[0].float() * fp8_ref.quantize_rows(h)[1][:, None] for h in heads.weights])
+        lm, oh = OracleLM(tq, "bf16"), hq
+    else:
+        lm, oh = OracleLM(tgt, "bf16"), heads.weights
+    oracle = OraclePipeline(lm, None, k=k, eos_token_id=tgt.config.eos_token_id, draft_mode="medusa_heads", medusa_heads=oh)
+    want = oracle.generate_batch(prompts, 24)
+    for b in range(batch):
+        assert got[b]["generated_tokens"] == want[b]["generated_tokens"], (k, b)
+        assert (got[b]["proposed"], got[b]["accepted"]) == (want[b]["proposed"], want[b]["accepted"])
+        greedy, _ = lm.generate_tokens(torch.tensor([prompts[b]]), len(got[b]["generated_tokens"]))
+        assert got[b]["generated_tokens"] == greedy[0].tolist()
+    acc = sum(r["accepted"] for r in got) / sum(r["proposed"] for r in got)
+    assert 0.5 < acc <= (k + 1) / k
+    single = pipe.generate(prompts[0], max_tokens=12, do_sample=False)
+    ws = oracle.generate(prompts[0], 12)
+    assert single["generated_tokens"] == ws["generated_tokens"]
+    assert (single["proposed"], single["accepted"], single["steps"]) == (ws["proposed"], ws["accepted"], ws["steps"])
