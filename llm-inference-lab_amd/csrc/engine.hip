@@ -503,7 +503,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     int n = 0;
     for (int b = 0; b < 256; ++b)
       if (h[b * 8]) { t0 = h[b * 8] < t0 ? h[b * 8] : t0; ++n; }
-    static const char* names[7] = {"entry", "issued", "staged", "mfma_done", "reduced", "epilogue", "end"};
+    static const char* names[7] = {"entry", "issued", "staged", "mfma_done", "reduced", "epilogue", "end"};  // gemm_skinny: issued = +statistics, staged = first chunk
     fprintf(stderr, "[timeline which=%d T=%d] %d workgroups, us from first entry (min / mean / max):\n", which, T, n);
     for (int s = 0; s < 7; ++s) {
       double mn = 1e30, mx = 0, sum = 0;

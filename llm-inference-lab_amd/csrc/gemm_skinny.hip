@@ -22,7 +22,9 @@
 
 namespace sd {
 
-template <int TG> struct SkBatch { static constexpr int value = (TG == 1) ? 8 : 4; };  // weight steps per batch (two batches in flight)
+// weight steps per batch NB (two batches in flight): 4 for <= 16 tokens when the chunk allows, else 2. Chunk
+// boundaries fall on batch starts (sc % NB == 0), so the staging code exists twice in the kernel, not once per
+// step: the kernels are instruction-fetch sensitive (36 -> 33 us for the 3B gate/up at 40 tokens from code size alone).
 constexpr int kSkMaxKc = 2048;
 
 struct SkinnyGeom {
@@ -53,7 +55,7 @@ static int skinny_chunk(int T, int K, int ksplit, int kw, bool w8 = false) {
 
 // W8: fp8 e4m3 weight storage (csrc/pack.hip) — a "step" is then one 16-byte load = 64 k = two MFMAs per
 // token group, widened to bf16 in registers as in gemv.hip; the row sum is scaled in the epilogue.
-template <int EPI, int TG, bool W8>
+template <int EPI, int TG, bool W8, int NB>
 __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArgs a, const SkinnyGeom sg) {
   constexpr int KS = W8 ? 64 : 32;   // k per weight step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
   // wave-local step s (chunk-major) -> global step
   auto gstep = [&](int s) { return ((s >> sc_shift) * ksplit + kpart) * sc + (s & (sc - 1)); };
 
-  constexpr int kSkBatch = SkBatch<TG>::value;
+  constexpr int kSkBatch = NB;
   u32x4 bufA[kSkBatch], bufB[kSkBatch];
   auto issue = [&](u32x4 (&buf)[kSkBatch], const uint16_t* ts, int s0) {
 #pragma unroll
@@ -119,41 +121,86 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
     }
   };
 
+  // diagnostic timeline (sd_model_probe_gemv with SPECDEC_GEMV_TIMELINE=1), as in gemv.hip:
+  // 0 entry, 1 weights issued + statistics done, 2 first chunk staged, 3 K loop done, 4 partials exchanged, 5 epilogue, 6 end
+  auto stamp = [&](int slot) {
+    if (a.debug_ts && tid == 0) a.debug_ts[static_cast<size_t>(blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   // ---- weights of round 0 first, then the norm statistics under their latency
   const uint16_t* ts0 = tile_start(tslot < n_tiles ? tslot : 0);
-  if (tslot < n_tiles) issue(bufA, ts0, 0);
 
   const uint16_t* xin = static_cast<const uint16_t*>(a.x);
   if (a.prologue != PRO_NONE) {
     const int nvec = K >> 3;
     const float invK = 1.0f / static_cast<float>(K);
-    for (int t = wave; t < T; t += kGemvWaves) {
-      const u32x4* src = reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t) * a.x_stride);
-      float s1 = 0.f, s2 = 0.f;
-      for (int v = lane; v < nvec; v += kWave) {
-        const u32x4 q = src[v];
+    // a wave takes rows wave, wave + 16, ... two at a time; the loads of both rows (<= 8 per lane each) are all
+    // issued before the first sum, so a pair costs one L2 round trip (row by row, load by load it was 6-8 us
+    // at 40 tokens: a third of the kernel)
+    constexpr int kMaxPer = 8;                       // 16-byte loads per lane per row held in registers (K <= 4096)
+    const int nper = (nvec + kWave - 1) / kWave;
+    constexpr int RR = 2;   // rows per pass
+    for (int tp = wave; tp < T; tp += RR * kGemvWaves) {
+      float s1[RR] = {0.f, 0.f}, s2[RR] = {0.f, 0.f};
+      if (nper <= kMaxPer) {
+        u32x4 q[RR][kMaxPer];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = __uint_as_float(q[j] << 16), hi = __uint_as_float(q[j] & 0xffff0000u);
-          s1 += lo + hi;
-          s2 += lo * lo + hi * hi;
+        for (int rr = 0; rr < RR; ++rr) {
+          const int t = tp + rr * kGemvWaves;
+          const u32x4* src = reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t < T ? t : T - 1) * a.x_stride);
+#pragma unroll
+          for (int i = 0; i < kMaxPer; ++i) {
+            const int v = lane + i * kWave;
+            q[rr][i] = (i < nper && v < nvec) ? src[v] : u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+          for (int i = 0; i < kMaxPer; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = __uint_as_float(q[rr][i][j] << 16), hi = __uint_as_float(q[rr][i][j] & 0xffff0000u);
+              s1[rr] += lo + hi;
+              s2[rr] += lo * lo + hi * hi;
+            }
+      } else {
+        for (int rr = 0; rr < RR; ++rr) {
+          const int t = tp + rr * kGemvWaves;
+          if (t >= T) break;
+          const u32x4* src = reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t) * a.x_stride);
+          for (int v = lane; v < nvec; v += kWave) {
+            const u32x4 qq = src[v];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = __uint_as_float(qq[j] << 16), hi = __uint_as_float(qq[j] & 0xffff0000u);
+              s1[rr] += lo + hi;
+              s2[rr] += lo * lo + hi * hi;
+            }
+          }
         }
       }
-      s1 = wave_reduce_sum(s1);
-      s2 = wave_reduce_sum(s2);
-      if (lane == 0) {
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+      const int t = tp + rr * kGemvWaves;
+      const float s1r = wave_reduce_sum(s1[rr]);
+      const float s2r = wave_reduce_sum(s2[rr]);
+      if (lane == 0 && t < T) {
         if (a.prologue == PRO_RMSNORM) {
           stat[2 * t] = 0.f;
-          stat[2 * t + 1] = rsqrtf(s2 * invK + a.norm_eps);
+          stat[2 * t + 1] = rsqrtf(s2r * invK + a.norm_eps);
         } else {
-          const float mean = s1 * invK;
+          const float mean = s1r * invK;
           stat[2 * t] = mean;
-          stat[2 * t + 1] = rsqrtf(fmaxf(s2 * invK - mean * mean, 0.f) + a.norm_eps);
+          stat[2 * t + 1] = rsqrtf(fmaxf(s2r * invK - mean * mean, 0.f) + a.norm_eps);
         }
+      }
       }
     }
   }
   // (the first chunk boundary's barrier publishes stat[])
+  if (tslot < n_tiles) issue(bufA, ts0, 0);   // after the statistics: their row loads need the registers
+  stamp(1);
 
   // ---- staging of chunk c: thread -> fixed 8-column block kv, tokens t0, t0 + tpi, ...
   const int kvec = kc >> 3;                 // power of two <= 256
@@ -166,8 +213,21 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
       nw4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + col);
       if (a.prologue == PRO_LAYERNORM) nb4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_b) + col);
     }
-    for (int t = t0; t < T; t += tpi) {
-      u32x4 q = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t) * a.x_stride + col);
+    // rows t0, t0 + tpi, ... GS at a time: their loads are issued together (one L2 round trip per group;
+    // load-normalise-store per row cost ~6 us per chunk at 40 tokens)
+    constexpr int GS = (TG <= 2) ? 4 : 2;   // rows per group (registers: the weight double buffer is live here)
+    for (int tb = t0; tb < T; tb += GS * tpi) {
+      u32x4 qg[GS];
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        const int t = tb + u * tpi;
+        qg[u] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(t < T ? t : T - 1) * a.x_stride + col);
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+      const int t = tb + u * tpi;
+      if (t >= T) break;
+      u32x4 q = qg[u];
       if (a.prologue == PRO_RMSNORM) {
         // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
         const float rs = stat[2 * t + 1];
@@ -189,6 +249,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
         }
       }
       *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + kv * 8) = q;
+      }
     }
   };
 
@@ -215,15 +276,16 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
     for (int q = 0; q < TG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     auto consume = [&](u32x4 (&buf)[kSkBatch], int s0) {
+      if (s0 < steps_w && (s0 & (sc - 1)) == 0) {  // chunk boundary (always a batch start): replace the staged chunk
+        __syncthreads();                           // every wave is done with the previous chunk (or partials)
+        stage(s0 >> sc_shift);
+        __syncthreads();
+        if (r == 0 && s0 == 0) stamp(2);
+      }
 #pragma unroll
       for (int j = 0; j < kSkBatch; ++j) {
         const int s = s0 + j;
         if (s < steps_w) {                       // workgroup-uniform
-          if ((s & (sc - 1)) == 0) {             // chunk boundary: replace the staged chunk
-            __syncthreads();                     // every wave is done with the previous chunk (or partials)
-            stage(s >> sc_shift);
-            __syncthreads();
-          }
           if (valid) {
             const int koff = (s & (sc - 1)) * KS;
             if constexpr (W8) {
@@ -262,6 +324,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
     }
 
     // K-slice partials through LDS (aliasing the chunk buffer)
+    if (r == 0) stamp(3);
     __syncthreads();
     float* slot = part + static_cast<size_t>(wave) * TG * 256;
 #pragma unroll
@@ -269,6 +332,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
 #pragma unroll
       for (int e = 0; e < 4; ++e) slot[q * 256 + (4 * g + e) * 16 + n] = acc[q][e];
     __syncthreads();
+    if (r == 0) stamp(4);
     for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
       const int tsl = it >> 7, jp = (it >> 4) & 7, tl = it & 15;  // tl == tid & 15 on every trip
       const int etile = r * tiles_per_round + tsl;
@@ -276,6 +340,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
       if (etile < n_tiles && jp < tile_pairs && p < p_hi) {
         int r0, r1;
         pair_rows<EPI>(a, p, r0, r1);
+        // residual epilogue: the old values of all token groups first (one round trip instead of TG)
+        uint32_t oldv[TG];
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+          for (int q = 0; q < TG; ++q) {
+            const int t = 16 * q + tl;
+            oldv[q] = *reinterpret_cast<const uint32_t*>(static_cast<const uint16_t*>(a.out) + static_cast<size_t>(t < T ? t : T - 1) * a.out_stride + r0);
+          }
+        }
 #pragma unroll
         for (int q = 0; q < TG; ++q) {
           const int t = 16 * q + tl;
@@ -290,13 +363,16 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
               y0 *= a.w_scale[r0];
               y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;
             }
-            epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
+            if constexpr (EPI == EPI_RESID) epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q], true, oldv[q]);
+            else epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
           }
         }
       }
     }
     // the next round's first chunk boundary (or the fold below) starts with a barrier
+    if (r == 0) stamp(5);
   }
+  stamp(6);
 
   if constexpr (EPI == EPI_ARGMAX) {
     // thread tid holds a running best for tokens 16 q + (tid & 15): fold the 64 candidates per token
@@ -461,26 +537,37 @@ static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
-template <int EPI, int TG, bool W8>
+template <int EPI, int TG, bool W8, int NB>
 static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG, W8>),
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG, W8, NB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG, W8>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG, W8, NB>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
 template <int EPI, bool W8>
 static int launch_skinny_w(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
+  const int sc = 1 << sg.sc_shift;   // steps per wave per chunk: batches must not straddle a chunk boundary
+  if (sc == 1) {
+    switch ((a.T + 15) / 16) {
+      case 1: return launch_skinny_one<EPI, 1, W8, 1>(a, sg, grid, smem, st);
+      case 2: return launch_skinny_one<EPI, 2, W8, 1>(a, sg, grid, smem, st);
+      case 3: return launch_skinny_one<EPI, 3, W8, 1>(a, sg, grid, smem, st);
+      default: return launch_skinny_one<EPI, 4, W8, 1>(a, sg, grid, smem, st);
+    }
+  }
   switch ((a.T + 15) / 16) {
-    case 1: return launch_skinny_one<EPI, 1, W8>(a, sg, grid, smem, st);
-    case 2: return launch_skinny_one<EPI, 2, W8>(a, sg, grid, smem, st);
-    case 3: return launch_skinny_one<EPI, 3, W8>(a, sg, grid, smem, st);
-    default: return launch_skinny_one<EPI, 4, W8>(a, sg, grid, smem, st);
+    case 1:
+      if (sc % 4 == 0) return launch_skinny_one<EPI, 1, W8, 4>(a, sg, grid, smem, st);
+      return launch_skinny_one<EPI, 1, W8, 2>(a, sg, grid, smem, st);
+    case 2: return launch_skinny_one<EPI, 2, W8, 2>(a, sg, grid, smem, st);
+    case 3: return launch_skinny_one<EPI, 3, W8, 2>(a, sg, grid, smem, st);
+    default: return launch_skinny_one<EPI, 4, W8, 2>(a, sg, grid, smem, st);
   }
 }
 

@@ -81,3 +81,22 @@ def test_kv_append_is_position_exact_at_full_size(full_pair):
     assert got_ids[0, len(prompt) - 1:].cpu().tolist() == seq[len(prompt):]
     a, b = got_logits[0, -1].float().cpu(), logits[0, -1].float().cpu()
     assert (a - b).abs().max().item() / b.abs().max().item() < 0.01
+
+
+def test_fp8_storage_at_full_size_multi_token_passes():
+    """fp8 weight storage on the 3B + 1B pair, batch 8 (40-token verify passes through the multi-token kernel
+    streaming fp8): the output is the fp8 target's own greedy continuation (1-token gemv.hip passes)."""
+    from specdec_hip import weights as W
+    from src.specdec import HipLM, SpeculativePipeline
+
+    tgt = W.synthetic_llama(W.LLAMA_3_2_3B, seed=0, device="cuda")
+    drf = W.synthetic_llama(W.LLAMA_3_2_1B, seed=1, device="cuda", embed_from=tgt, flip_fraction=0.2)
+    target_lm, draft_lm = HipLM(tgt, weight_dtype="fp8"), HipLM(drf, weight_dtype="fp8")
+    assert target_lm.new_engine(1, 64).pass_tokens == 64
+    prompts = synthetic_prompts(8, 32, target_lm.vocab_size).tolist()
+    pipe = SpeculativePipeline(base_lm=target_lm, draft_lm=draft_lm, controller="fixed", controller_params={"k": 4}, seed=1234)
+    got = pipe.generate_batch(prompts, max_tokens=32, do_sample=False)
+    want = _reference_greedy(target_lm, prompts[:2], 40)
+    for b, w in enumerate(want):
+        g = got[b]["generated_tokens"]
+        assert len(g) >= 32 and g == w[: len(g)], b
