@@ -68,10 +68,27 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
   return *reinterpret_cast<uint16_t*>(&h);
 }
 
-__device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Sum over the 64 lanes, result in every lane. Data-parallel-primitive moves on the VALU (v_add_f32 with a DPP
+// operand), not __shfl_xor: that lowers to ds_bpermute_b32, which occupies the LDS pipe — with 16 waves per CU
+// doing 2 x T reductions in the norm prologue of every GEMV the LDS pipe, not HBM, set the prologue's length
+// (7 us at 5 tokens, measured with the in-kernel timeline).
+#define SD_DPP_F32(v, old, ctrl, row_mask) \
+  __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), ctrl, row_mask, 0xf, false))
+
+// sum over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row16_reduce_sum(float v) {
+  v += SD_DPP_F32(v, v, 0xb1, 0xf);    // quad_perm:[1,0,3,2]
+  v += SD_DPP_F32(v, v, 0x4e, 0xf);    // quad_perm:[2,3,0,1]
+  v += SD_DPP_F32(v, v, 0x124, 0xf);   // row_ror:4
+  v += SD_DPP_F32(v, v, 0x128, 0xf);   // row_ror:8
   return v;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+  v = row16_reduce_sum(v);
+  v += SD_DPP_F32(v, 0.f, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  v += SD_DPP_F32(v, 0.f, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float wave_reduce_max(float v) {

@@ -35,6 +35,7 @@ struct sd_model {
   uint16_t* q = nullptr;     // [64][Hq*D]
   uint16_t* attn = nullptr;  // [64][Hq*D]
   uint16_t* act = nullptr;   // [64][ff]
+  int32_t* probe_pos = nullptr;  // [1] zero: position base of the QKV probe
   float* attn_ws = nullptr;      // split-KV partial tiles (attention.hip)
   unsigned* attn_cnt = nullptr;  // arrival counters, zero between launches
   float* part_val = nullptr; // [64][512]
@@ -404,6 +405,7 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->attn_ws = reinterpret_cast<float*>(p);
   m->attn_cnt = reinterpret_cast<unsigned*>(p + static_cast<size_t>(kAttnSplitSlots) * 16 * (c.head_dim + 2) * sizeof(float));
   SD_HIP_CHECK(hipMemset(m->attn_cnt, 0, kAttnSplitSlots * sizeof(unsigned)));
+  m->probe_pos = reinterpret_cast<int32_t*>(m->attn_cnt);   // a zero word (the counters rest at zero between launches)
   return 0;
 }
 
@@ -443,12 +445,24 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     g.packed = m->is_packed();
     g.w8 = m->w8();
     g.w_scale = m->scale(which == 4 ? 4 * c.n_layers : 4 * (l % c.n_layers) + which);
+    g.M = T;
     const int li = l % c.n_layers;
     g.T = T;
     g.M = T;
     g.out_dtype = SD_BF16;
     g.norm_eps = c.norm_eps;
     switch (which) {
+      case 0: {  // norm + QKV projection + RoPE + in-place KV append (row 0 of the cache, positions 0..T-1)
+        const int Hkv = c.n_kv_heads;
+        g.W = m->mat(4 * li + 0, w.wqkv); g.bias = w.bqkv; g.N = (Hq + 2 * Hkv) * D; g.K = d; g.n_pairs = g.N / 2;
+        g.x = m->x; g.x_stride = d; g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.attn_norm_w; g.norm_b = w.attn_norm_b;
+        g.out = m->q; g.out_stride = Hq * D; g.head_dim = D; g.n_q_heads = Hq; g.n_kv_heads = Hkv; g.max_pos = c.max_pos; g.l_max = m->Lmax;
+        g.rope_cos = llama ? c.rope_cos : nullptr; g.rope_sin = llama ? c.rope_sin : nullptr;
+        g.pos_base = m->probe_pos; g.pos_off = 0; g.M = T;
+        const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+        g.k_cache = m->k_cache + li * layer_kv; g.v_cache = m->v_cache + li * layer_kv;
+        return launch_gemv(g, EPI_QKV_ROPE, st);
+      }
       case 1:  // attention output projection + residual
         g.W = m->mat(4 * li + 1, w.wo); g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
         g.x = m->attn; g.x_stride = Hq * D; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
@@ -470,12 +484,13 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
         g.part_val = m->part_val; g.part_idx = m->part_idx;
         return launch_gemv(g, EPI_ARGMAX, st);
       default:
-        set_error("probe_gemv: which=%d (1=o_proj 2=gate_up 3=down 4=lm_head)", which);
+        set_error("probe_gemv: which=%d (0=qkv 1=o_proj 2=gate_up 3=down 4=lm_head)", which);
         return 1;
     }
   };
   double bytes = 0;
   switch (which) {
+    case 0: bytes = 2.0 * (Hq + 2 * c.n_kv_heads) * D * d; break;
     case 1: bytes = 2.0 * d * Hq * D; break;
     case 2: bytes = 2.0 * (llama ? 2 : 1) * ff * d; break;
     case 3: bytes = 2.0 * d * ff; break;

@@ -85,12 +85,8 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
   const uint16_t* nb = static_cast<const uint16_t*>(a.norm_b);
   const float invK = 1.0f / static_cast<float>(K);
   for (int t = 0; t < T; ++t) {
-    float sum = 0.f, sq = 0.f;
-#pragma unroll
-    for (int w = 0; w < kGemvWaves; ++w) {
-      sum += red[(t * kGemvWaves + w) * 2 + 0];
-      sq += red[(t * kGemvWaves + w) * 2 + 1];
-    }
+    const float2 pr = *reinterpret_cast<const float2*>(red + (t * kGemvWaves + (lane & 15)) * 2);
+    const float sum = row16_reduce_sum(pr.x), sq = row16_reduce_sum(pr.y);
     uint16_t* row = xs + static_cast<size_t>(t) * KP;
     if (a.prologue == PRO_RMSNORM) {
       const float rs = rsqrtf(sq * invK + a.norm_eps);
@@ -243,11 +239,18 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   uint32_t old_pre = 0;
   if constexpr (fast_stage) {
     const uint16_t* xin = static_cast<const uint16_t*>(a.x);
+    if (a.x_row) {   // kernel-uniform: gathered rows (Medusa heads read the accepted position's hidden row)
+      int rows[TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      const int tt = (t < T) ? t : T - 1;
-      const int xrow_i = a.x_row ? a.x_row[tt] : tt;   // gathered rows (Medusa heads read the accepted position's hidden row)
-      xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(xrow_i) * a.x_stride + cidx * 8);
+      for (int t = 0; t < TT; ++t) rows[t] = a.x_row[(t < T) ? t : T - 1];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(rows[t]) * a.x_stride + cidx * 8);
+    } else {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int tt = (t < T) ? t : T - 1;
+        xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(tt) * a.x_stride + cidx * 8);
+      }
     }
     if (a.prologue != PRO_NONE) {  // kernel-uniform
       nw4 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + cidx * 8);
@@ -281,20 +284,25 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       if (t < T && has_chunk) *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + tid * 8) = xr[t];
     __syncthreads();
   } else {
-    // per-row sum / sum of squares: own chunk -> wave -> LDS -> every thread
+    // per-row sum / sum of squares: own chunk -> wave -> LDS -> every thread. Only the first nvec/64 waves own
+    // chunks (6 of 16 at K = 3072); the others skip the arithmetic — all 16 waves running the ~100 VALU
+    // instructions per token on clamped duplicates made the prologue VALU-bound (4 us at 5 tokens).
+    const bool wave_has_chunk = (wave << 6) < nvec;   // wave-uniform
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       if (t < T) {
         float s1 = 0.f, s2 = 0.f;
+        if (wave_has_chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = __uint_as_float(xr[t][j] << 16), hi = __uint_as_float(xr[t][j] & 0xffff0000u);
-          s1 += lo + hi;
-          s2 += lo * lo + hi * hi;
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(xr[t][j] << 16), hi = __uint_as_float(xr[t][j] & 0xffff0000u);
+            s1 += lo + hi;
+            s2 += lo * lo + hi * hi;
+          }
+          if (!has_chunk) { s1 = 0.f; s2 = 0.f; }  // clamped (duplicate) loads do not count
+          s1 = wave_reduce_sum(s1);
+          s2 = wave_reduce_sum(s2);
         }
-        if (!has_chunk) { s1 = 0.f; s2 = 0.f; }  // clamped (duplicate) loads do not count
-        s1 = wave_reduce_sum(s1);
-        s2 = wave_reduce_sum(s2);
         if (lane == 0) {
           red[(t * kGemvWaves + wave) * 2 + 0] = s1;
           red[(t * kGemvWaves + wave) * 2 + 1] = s2;
@@ -305,13 +313,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     const float invK = 1.0f / static_cast<float>(K);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      if (t < T) {
-        float sum = 0.f, sq = 0.f;
-#pragma unroll
-        for (int w = 0; w < kGemvWaves; ++w) {
-          sum += red[(t * kGemvWaves + w) * 2 + 0];
-          sq += red[(t * kGemvWaves + w) * 2 + 1];
-        }
+      if (t < T && wave_has_chunk) {
+        // the 16 per-wave partials: lane l reads partial l & 15 (one 8-byte LDS read), rows of 16 lanes add up
+        const float2 pr = *reinterpret_cast<const float2*>(red + (t * kGemvWaves + (lane & 15)) * 2);
+        const float sum = row16_reduce_sum(pr.x), sq = row16_reduce_sum(pr.y);
         u32x4 o;
         if (a.prologue == PRO_RMSNORM) {
           // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
