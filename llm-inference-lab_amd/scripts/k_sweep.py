@@ -97,7 +97,17 @@ def run(args):
             for b0 in range(0, len(PROMPT_SUITE), batch):
                 idxs = list(range(b0, min(b0 + batch, len(PROMPT_SUITE))))
                 prompts = [prompt_ids(base, PROMPT_SUITE[i], i) for i in idxs]
-                outs = pipe.generate_batch(prompts, max_tokens=args.max_tokens, temperature=0.7, do_sample=False)
+                if args.continuous:   # all prompts at once through `batch` slots (a finished row's slot is re-used)
+                    if b0 != 0:
+                        continue
+                    idxs = list(range(len(PROMPT_SUITE)))
+                    prompts = [prompt_ids(base, PROMPT_SUITE[i], i) for i in idxs]
+                    outs = pipe.generate_many(prompts, max_tokens=args.max_tokens, batch_size=batch, do_sample=False)
+                    for o in outs:
+                        o.setdefault("kv_appended_tokens", o["num_generated"])
+                        o.setdefault("kv_append_time_ms", 0.0)
+                else:
+                    outs = pipe.generate_batch(prompts, max_tokens=args.max_tokens, temperature=0.7, do_sample=False)
                 for i, r in zip(idxs, outs):
                     row = {
                         "k": k, "iteration": it + 1, "prompt_idx": i + 1, "prompt_name": PROMPT_SUITE[i],
@@ -161,6 +171,8 @@ if __name__ == "__main__":
     ap.add_argument("--max-tokens", type=int, default=64)
     ap.add_argument("--iterations", type=int, default=1)
     ap.add_argument("--batch-size", type=int, default=1)
+    ap.add_argument("--continuous", action="store_true",
+                    help="continuous batching (generate_many) instead of the reference harness' fixed batches")
     ap.add_argument("--output-dir", default="gpurun_out/k_sweep")
     a = ap.parse_args()
     if not a.draft_model.startswith("synthetic:"):
