@@ -293,14 +293,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       if (t < T) {
         float s1 = 0.f, s2 = 0.f;
         if (wave_has_chunk) {
+          const bool need_mean = a.prologue == PRO_LAYERNORM;   // kernel-uniform: RMSNorm only needs the squares
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float lo = __uint_as_float(xr[t][j] << 16), hi = __uint_as_float(xr[t][j] & 0xffff0000u);
-            s1 += lo + hi;
+            if (need_mean) s1 += lo + hi;
             s2 += lo * lo + hi * hi;
           }
           if (!has_chunk) { s1 = 0.f; s2 = 0.f; }  // clamped (duplicate) loads do not count
-          s1 = wave_reduce_sum(s1);
+          if (need_mean) s1 = wave_reduce_sum(s1);
           s2 = wave_reduce_sum(s2);
         }
         if (lane == 0) {
