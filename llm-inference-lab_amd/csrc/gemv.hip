@@ -34,12 +34,21 @@
 //     residual / logits stores. Rows 0..7 of a tile are the first rows of its
 //     pairs, rows 8..15 the second rows.
 
+#include <stdlib.h>
+
 #include "gemv_device.h"
 
 namespace sd {
 
-constexpr int kBatch = 12;                        // loads in flight per lane
-constexpr int kPre = 8;                           // of which issued before the prologue
+// Loads in flight per lane (template parameter KB) and how many of them are issued before the prologue (kPre).
+// Swept on the whole step with a low-noise bench (3B + 1B, K=4, ms/step): KB = 4..12 -> 4.66 4.69 4.64 4.68 4.67 4.77
+// 4.77 4.80 4.82 (14 spills): the many small launches of a step want a SHALLOW batch (less queueing in front
+// of their few loads), while a long stream alone is ~5 % faster with 12 (lm_head 120 vs 126 us). So: 12 for matrices
+// with >= kDeepSteps steps per wave, 6 otherwise (threshold swept on one box: never / 48 / 24 / 16 -> 4.65 / 4.65 /
+// 4.61 / 4.67 ms per step).
+constexpr int kBatchShallow = 6, kBatchDeep = 12;
+constexpr int kPre = 8;
+constexpr int kDeepSteps = 24;
 
 // ------------------------------------------------------------------------------
 // staging of x into LDS (bf16 [T][K + pad]) with the fused normalisation
@@ -129,8 +138,9 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
 //   holds its A fragments of two consecutive 32-k steps; they are widened to bf16 in registers
 //   (v_cvt_scalef32_pk_bf16_fp8, exact) and feed two bf16 MFMAs; the fp32 sum of row r is scaled by
 //   w_scale[r] in the epilogue. Half the HBM bytes per token, bf16 activations unchanged.
-template <int EPI, bool MASK, int TT, bool W8>
+template <int EPI, bool MASK, int TT, bool W8, int KB>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
+  constexpr int kBatch = KB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
   const int KP = K + kXPad;
@@ -473,33 +483,36 @@ int gemv_grid(const GemvArgs& a, int* ppw_out) {
   return q.grid;
 }
 
-template <int EPI, bool MASK, int TT, bool W8>
+template <int EPI, bool MASK, int TT, bool W8, int KB>
 static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into once per kernel
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT, W8>),
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT, W8, KB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8, KB>), dim3(grid), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 
-template <int EPI, bool W8>
+template <int EPI, bool W8, int KB>
 static int launch_epi_w(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
-  if (mask) return launch_one<EPI, true, kGemvMaxT, W8>(a, grid, smem, st);  // generic shapes: one variant
-  if (a.T <= 1) return launch_one<EPI, false, 1, W8>(a, grid, smem, st);
-  if (a.T <= 2) return launch_one<EPI, false, 2, W8>(a, grid, smem, st);
-  if (a.T <= 3) return launch_one<EPI, false, 3, W8>(a, grid, smem, st);
-  if (a.T <= 5) return launch_one<EPI, false, 5, W8>(a, grid, smem, st);
-  return launch_one<EPI, false, kGemvMaxT, W8>(a, grid, smem, st);
+  if (mask) return launch_one<EPI, true, kGemvMaxT, W8, KB>(a, grid, smem, st);  // generic shapes: one variant
+  if (a.T <= 1) return launch_one<EPI, false, 1, W8, KB>(a, grid, smem, st);
+  if (a.T <= 2) return launch_one<EPI, false, 2, W8, KB>(a, grid, smem, st);
+  if (a.T <= 3) return launch_one<EPI, false, 3, W8, KB>(a, grid, smem, st);
+  if (a.T <= 5) return launch_one<EPI, false, 5, W8, KB>(a, grid, smem, st);
+  return launch_one<EPI, false, kGemvMaxT, W8, KB>(a, grid, smem, st);
 }
 
 template <int EPI>
 static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
-  return a.w8 ? launch_epi_w<EPI, true>(a, mask, grid, smem, st) : launch_epi_w<EPI, false>(a, mask, grid, smem, st);
+  static const int deep_steps = getenv("SPECDEC_GEMV_DEEP_STEPS") ? atoi(getenv("SPECDEC_GEMV_DEEP_STEPS")) : kDeepSteps;
+  const bool deep = (a.kw >> (a.w8 ? 6 : 5)) >= deep_steps;   // loads per wave over the whole K slice
+  if (a.w8) return deep ? launch_epi_w<EPI, true, kBatchDeep>(a, mask, grid, smem, st) : launch_epi_w<EPI, true, kBatchShallow>(a, mask, grid, smem, st);
+  return deep ? launch_epi_w<EPI, false, kBatchDeep>(a, mask, grid, smem, st) : launch_epi_w<EPI, false, kBatchShallow>(a, mask, grid, smem, st);
 }
 
 int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {

@@ -272,6 +272,8 @@ class HipSpecDec:
         return self._logits
 
     def step(self, use_graph: bool = True, two_streams: bool = True):
+        if os.environ.get("SPECDEC_ONE_STREAM"):   # experiment knob: draft and verify on one stream (no fork/join events)
+            two_streams = False
         with torch.cuda.device(self.device):
             sd = self.stream_d.cuda_stream if two_streams else None
             _abi.check(self.lib.sd_specdec_step(self.handle, self.stream_t.cuda_stream, sd,
