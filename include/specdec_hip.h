@@ -316,10 +316,17 @@ int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* const* packed_
  * into a hipGraph on first use and replayed afterwards. */
 int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_draft, int use_graph);
 
+/* Steps launched so far, and a wait for ONE of the last two launches (0-based index) without draining the stream:
+ * the host may keep a second step queued behind the running one (the device advances its own state) and still read
+ * the record of the older one — slot (index & 1) of sd_specdec_record. */
+long sd_specdec_launches(const sd_specdec* s);
+int sd_specdec_wait(sd_specdec* s, long launch_index);
+
 /* Block until everything enqueued on `stream` is done (hipStreamSynchronize). */
 int sd_specdec_sync(sd_specdec* s, void* stream);
 
-/* Pinned host record of the last completed step, ints per row:
+/* Pinned host records, written by the device at the end of each step: TWO slots of [B][record_ints], the
+ * record of launch i (0-based, sd_specdec_launches) is in slot i & 1. Ints per row:
  *   [0] accept_len  [1] n_new  [2] cur_len after the step
  *   [3 .. 3+K]            emitted tokens (n_new valid, -1 padded)
  *   [4+K .. 3+2K]         draft tokens d_1..d_K

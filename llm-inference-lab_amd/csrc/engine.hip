@@ -540,8 +540,10 @@ struct sd_specdec {
   int B = 0, K = 0, mode = 0;
   SpecState st{};
   int32_t* dev_block = nullptr;   // all device state in one allocation
-  int32_t* dev_record = nullptr;  // [B][rec]
-  int32_t* host_record = nullptr; // pinned
+  int32_t* step_counter = nullptr; // device: steps executed (its parity selects the record slot)
+  int32_t* host_record = nullptr;  // pinned, device-accessible: [2 slots][B][rec]
+  hipEvent_t ev_done[2] = {nullptr, nullptr};   // recorded after launch i on the target stream (i & 1)
+  long launches = 0;
   int32_t* host_stage = nullptr;  // pinned staging for set_row
   int rec = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -565,20 +567,28 @@ struct sd_specdec {
 
 namespace sd {
 
-__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec, int rec_ints) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// The step record, written straight into pinned host memory (device-accessible). Two slots, selected by the parity
+// of a device-resident step counter, so that the host can still read step s while step s+1 (launched ahead) writes
+// its own. One wave walks the rows, then advances the counter.
+__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec_slots, int rec_ints, int32_t* step_counter) {
+  const int lane = threadIdx.x;
   const int K = s.K;
-  int32_t* r = rec + static_cast<size_t>(b) * rec_ints;
-  if (lane == 0) {
-    r[0] = s.accept_len[b];
-    r[1] = s.n_new[b];
-    r[2] = s.cur_len[b];
+  const int slot = *step_counter & 1;
+  int32_t* rec = rec_slots + static_cast<size_t>(slot) * s.B * rec_ints;
+  for (int b = 0; b < s.B; ++b) {
+    int32_t* r = rec + static_cast<size_t>(b) * rec_ints;
+    if (lane == 0) {
+      r[0] = s.accept_len[b];
+      r[1] = s.n_new[b];
+      r[2] = s.cur_len[b];
+    }
+    if (lane <= K) {
+      r[3 + lane] = s.new_tok[b * (K + 1) + lane];
+      r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
+    }
+    if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
   }
-  if (lane <= K) {
-    r[3 + lane] = s.new_tok[b * (K + 1) + lane];
-    r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
-  }
-  if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
+  if (lane == 0) *step_counter = *step_counter + 1;
 }
 
 // draft tokens of the NEXT step from the heads: d_{i+1} = argmax head_i(final_norm(h)), h = the residual row of the
@@ -657,9 +667,8 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
       return rc;
   }
   if (int rc = launch_accept(s->st, s->mode, s->sample, st_t)) return rc;
-  hipLaunchKernelGGL(pack_record_kernel, dim3(B), dim3(kWave), 0, st_t, s->st, s->dev_record, s->rec);
+  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(kWave), 0, st_t, s->st, s->host_record, s->rec, s->step_counter);
   SD_LAUNCH_CHECK();
-  SD_HIP_CHECK(hipMemcpyAsync(s->host_record, s->dev_record, sizeof(int32_t) * B * s->rec, hipMemcpyDeviceToHost, st_t));
   // persistent Medusa heads: the proposals of the next step, after the record of this one has left
   if (!s->heads.empty())
     if (int rc = enqueue_medusa_heads(s, st_t)) return rc;
@@ -686,7 +695,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   s->mode = emit_mode;
   s->rec = 5 + 3 * K;
   const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1) + 1);
-  const size_t n_total = n_state + static_cast<size_t>(B) * s->rec;
+  const size_t n_total = n_state + 4;
   hipError_t e = hipMalloc(&s->dev_block, n_total * sizeof(int32_t));
   if (e != hipSuccess) {
     delete s;
@@ -709,8 +718,10 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   st.n_new = p; p += B;
   st.new_tok = p; p += static_cast<size_t>(B) * (K + 1);
   st.sampled = p; p += B;
-  s->dev_record = p;
-  if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * B * s->rec, hipHostMallocDefault) != hipSuccess ||
+  s->step_counter = p;
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * 2 * B * s->rec, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * 8, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -725,6 +736,8 @@ extern "C" int sd_specdec_destroy(sd_specdec* s) {
   if (!s) return 0;
   if (s->exec) (void)hipGraphExecDestroy(s->exec);
   if (s->graph) (void)hipGraphDestroy(s->graph);
+  if (s->ev_done[0]) (void)hipEventDestroy(s->ev_done[0]);
+  if (s->ev_done[1]) (void)hipEventDestroy(s->ev_done[1]);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->host_record) (void)hipHostFree(s->host_record);
@@ -829,7 +842,10 @@ extern "C" int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_
   if (!use_graph || s->steps == 1) {
     // the first step always runs eagerly: it also performs the one-time kernel
     // attribute setup that must not happen inside a capture
-    return enqueue_step(s, st_t, st_d);
+    if (int rc = enqueue_step(s, st_t, st_d)) return rc;
+    SD_HIP_CHECK(hipEventRecord(s->ev_done[s->launches & 1], st_t));
+    s->launches++;
+    return 0;
   }
   if (s->exec && (s->graph_st_t != st_t || s->graph_st_d != st_d)) {
     (void)hipGraphExecDestroy(s->exec);
@@ -853,6 +869,19 @@ extern "C" int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_
     s->graph_st_d = st_d;
   }
   SD_HIP_CHECK(hipGraphLaunch(s->exec, st_t));
+  SD_HIP_CHECK(hipEventRecord(s->ev_done[s->launches & 1], st_t));   // completion of THIS step (sd_specdec_wait)
+  s->launches++;
+  return 0;
+}
+
+extern "C" long sd_specdec_launches(const sd_specdec* s) { return s ? s->launches : 0; }
+
+extern "C" int sd_specdec_wait(sd_specdec* s, long launch_index) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_wait: NULL");
+  SD_REQUIRE(launch_index >= 0 && launch_index < s->launches && launch_index + 2 >= s->launches,
+             "specdec_wait: step %ld is not one of the last two launches (%ld launched)", launch_index, s->launches);
+  SD_HIP_CHECK(hipEventSynchronize(s->ev_done[launch_index & 1]));
   return 0;
 }
 
@@ -863,6 +892,7 @@ extern "C" int sd_specdec_sync(sd_specdec* s, void* stream) {
   return 0;
 }
 
+// two slots of [B][record_ints]: the record of launch i is in slot i & 1
 extern "C" const int32_t* sd_specdec_record(const sd_specdec* s) { return s ? s->host_record : nullptr; }
 
 extern "C" int sd_specdec_record_ints(const sd_specdec* s) { return s ? s->rec : 0; }

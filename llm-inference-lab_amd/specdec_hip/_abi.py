@@ -88,6 +88,8 @@ SIGNATURES = {
     "sd_pack_head": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_size, _c_void_p]),
     "sd_specdec_step": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int]),
     "sd_specdec_sync": (_c_int, [_c_void_p, _c_void_p]),
+    "sd_specdec_launches": (ctypes.c_long, [_c_void_p]),
+    "sd_specdec_wait": (_c_int, [_c_void_p, ctypes.c_long]),
     "sd_specdec_record": (ctypes.POINTER(ctypes.c_int32), [_c_void_p]),
     "sd_specdec_record_ints": (_c_int, [_c_void_p]),
 }

@@ -210,7 +210,7 @@ class HipSpecDec:
             self.stream_d = torch.cuda.Stream(self.device)
         self.rec_ints = self.lib.sd_specdec_record_ints(self.handle)
         ptr = self.lib.sd_specdec_record(self.handle)
-        self._record = np.ctypeslib.as_array(ptr, shape=(self.B, self.rec_ints))
+        self._record = np.ctypeslib.as_array(ptr, shape=(2, self.B, self.rec_ints))   # slot = launch index & 1
 
     def join_current_stream(self):
         """Order the loop's streams after work already enqueued on torch's current
@@ -280,9 +280,21 @@ class HipSpecDec:
                                                 1 if use_graph else 0), "sd_specdec_step")
 
     def sync(self) -> StepRecord:
+        """Drain the loop's stream; the record of the LAST launched step."""
         with torch.cuda.device(self.device):
             _abi.check(self.lib.sd_specdec_sync(self.handle, self.stream_t.cuda_stream), "sd_specdec_sync")
-        return StepRecord(self._record, self.K)
+        last = max(int(self.lib.sd_specdec_launches(self.handle)) - 1, 0)
+        return StepRecord(self._record[last & 1], self.K)
+
+    @property
+    def launches(self) -> int:
+        return int(self.lib.sd_specdec_launches(self.handle))
+
+    def wait(self, launch_index: int) -> StepRecord:
+        """Wait for one of the last two launched steps (the other may still be running) and return its record."""
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_wait(self.handle, int(launch_index)), "sd_specdec_wait")
+        return StepRecord(self._record[launch_index & 1], self.K)
 
     def close(self):
         if getattr(self, "handle", None):

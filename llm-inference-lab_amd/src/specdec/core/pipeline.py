@@ -465,15 +465,17 @@ class SpeculativePipeline:
 class DecodeSession:
     """One batch of rows being decoded: host mirror of the sequences + the device loop.
 
-    The device advances its own state at the end of a step, so the NEXT step does not need anything
-    from the host. With a fixed K and greedy decoding `advance()` therefore launches step s+1 as soon as
-    the record of step s has arrived and applies the reference's host rules to that record while the GPU
-    is already running: the host's turn (rules, bookkeeping, most of the graph-launch call) leaves the
-    critical path. When the rules change a row (it finishes, or a de-duplication rewrites it), the step
-    already in flight is void FOR THAT ROW: its record is ignored, the row's device state is repaired at
-    the next launch point (the stream is idle there), and it rejoins one step later. Steps are counted
-    per row, so the reference's step bound applies to each row's own valid steps. Adaptive K and the
-    sampled mode keep the launch -> wait -> rules order (the next launch depends on the host there)."""
+    The device advances its own state at the end of a step, so the NEXT steps do not need anything from
+    the host. With a fixed K and greedy decoding `advance()` therefore keeps up to two steps launched: while
+    the host applies the reference's rules to the record of step s, step s+1 is running and step s+2 is
+    queued behind it (records land in two alternating pinned slots, each launch has its own completion
+    event) — the GPU never waits for the host's turn. When the rules change a row (it finishes, or a
+    de-duplication rewrites it), the steps already launched are void FOR THAT ROW: their records are
+    ignored for it, no further step is launched until the queue has drained, the row's device state is
+    repaired there (idle stream) and it rejoins. Steps are counted per row, so the reference's step bound
+    applies to each row's own valid steps. Adaptive K, the sampled mode and the persistent Medusa heads
+    keep the launch -> wait -> rules order (their next launch depends on the host, or on counters that a void
+    step would disturb)."""
 
     def __init__(self, pipe: SpeculativePipeline, prompts: List[List[int]], max_tokens: int, emit_mode: int,
                  sampling: Optional[Dict[str, Any]] = None, step_limit: Optional[int] = None, self_draft: bool = False):
@@ -513,9 +515,13 @@ class DecodeSession:
         self._early = (isinstance(ctl, FixedKController) and sampling is None
                        and not (self_draft and pipe.medusa_heads is not None)
                        and os.environ.get("SPECDEC_EARLY_LAUNCH", "1") != "0")
-        self._inflight = False
+        self._depth = 2 if self._early else 1
+        if os.environ.get("SPECDEC_LAUNCH_DEPTH"):
+            self._depth = max(1, min(2, int(os.environ["SPECDEC_LAUNCH_DEPTH"])))
+        from collections import deque
+
+        self._queue = deque()                # launched, not yet consumed: (launch index, set of rows it is void for)
         self._flagged: Dict[int, str] = {}   # rows whose device state must be repaired before the next launch
-        self._void: set = set()              # rows for which the step in flight is void
 
     def any_active(self) -> bool:
         return any(r.active for r in self.rows)
@@ -556,26 +562,36 @@ class DecodeSession:
             pipe._set_row(loop, b, r)              # (re)position, or freeze a finished row
         self._flagged.clear()
 
-    def _launch(self) -> None:
-        self._repair_rows()
-        if getattr(self, "_resample_state", False):
-            self._resample_state = False
-            self._apply_sampling()
-        self.loop.step(use_graph=True)
-        self._inflight = True
-        self._void = set()
+    @property
+    def _inflight(self) -> bool:
+        return bool(self._queue)
 
-    def _next_step_is_needed(self) -> bool:
-        """Conservative: some row cannot finish in the step whose record is about to be processed."""
+    def _launch(self) -> None:
+        """Only with an empty queue are repairs possible (idle stream); callers guarantee it when rows are flagged."""
+        if self._flagged or getattr(self, "_resample_state", False):
+            assert not self._queue
+            self._repair_rows()
+            if getattr(self, "_resample_state", False):
+                self._resample_state = False
+                self._apply_sampling()
+        idx = self.loop.launches
+        self.loop.step(use_graph=True)
+        self._queue.append((idx, set()))
+
+    def _can_launch_ahead(self) -> bool:
+        """Conservative: some row cannot finish within the steps already launched, and nothing waits for a repair."""
+        if self._flagged or getattr(self, "_resample_state", False):
+            return False
+        ahead = len(self._queue) + 1       # steps whose records are still to come, counting the one being considered
         per_step = self.k + 1 if self.emit_mode == HipSpecDec.EMIT_BONUS else self.k
         for b, r in enumerate(self.rows):
-            if not r.active or b in self._flagged:
+            if not r.active:
                 continue
-            if len(r.generated) + per_step >= self.max_tokens:
+            if len(r.generated) + ahead * per_step >= self.max_tokens:
                 continue
-            if self.step_limit is not None and r.steps + 2 > self.step_limit:
+            if self.step_limit is not None and r.steps + ahead + 1 > self.step_limit:
                 continue
-            if len(r.seq) + 3 * self.k + 6 > self.pos_limit:
+            if len(r.seq) + (ahead + 2) * self.k + 6 > self.pos_limit:
                 continue
             return True
         return False
@@ -603,14 +619,15 @@ class DecodeSession:
                 self._apply_sampling()
         k, loop, rt = self.k, self.loop, self.rt
         t0 = time.time()
-        if not self._inflight:
-            self._launch()
-        rec = loop.sync()
-        self._inflight = False
-        void = self._void
+        if not self._queue:
+            self._launch()              # (repairs flagged rows first: the stream is idle)
+        while self._early and len(self._queue) < self._depth and self._can_launch_ahead():
+            self._launch()              # keep the GPU's queue ahead of the host
+        idx, void = self._queue.popleft()
+        rec = loop.wait(idx) if self._queue else loop.sync()
         self.last_record = rec
-        if self._early and self._next_step_is_needed():
-            self._launch()          # step s+1 runs while the rules of step s are applied below
+        while self._early and len(self._queue) < self._depth and self._can_launch_ahead():
+            self._launch()              # step s+1 (s+2) runs while the rules of step s are applied below
         stats["device_ms"] += (time.time() - t0) * 1e3
         for b, r in enumerate(rows):
             if not r.active:
@@ -644,8 +661,9 @@ class DecodeSession:
             elif r.seq != assumed:
                 stats["resyncs"] += 1
                 self._flagged[b] = "resync"
-            if b in self._flagged and self._inflight:
-                self._void.add(b)
+            if b in self._flagged:
+                for _, vs in self._queue:      # every step already launched is void for this row
+                    vs.add(b)
         stats["steps"] = max(r.steps for r in rows)
         return True
 
@@ -660,14 +678,14 @@ class DecodeSession:
             raise ValueError(f"prompt of {len(prompt)} tokens does not fit this session (l_max {self.rt['l_max']}, positions {self.pos_limit})")
         self.rows[b] = _Row(list(prompt))
         self._flagged[b] = "resync"
-        if self._inflight:
-            self._void.add(b)
+        for _, vs in self._queue:
+            vs.add(b)
         if self.sampling is not None:
             self._resample_state = True   # draw counters restart for the new row at the next launch point
 
     def finish(self) -> None:
         """Drain a step launched ahead of a run that ended, and leave the device rows consistent."""
-        if self._inflight:
+        if self._queue:
             self.loop.sync()
-            self._inflight = False
+            self._queue.clear()
         self._repair_rows()
