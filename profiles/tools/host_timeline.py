@@ -41,7 +41,17 @@ def sync():
     return r
 
 
-loop.step, loop.sync = step, sync
+orig_wait = loop.wait
+
+
+def wait(i):
+    t = time.perf_counter()
+    r = orig_wait(i)
+    acc["wait"] += time.perf_counter() - t
+    return r
+
+
+loop.step, loop.sync, loop.wait = step, sync, wait
 t0 = time.perf_counter()
 for _ in range(N):
     sess.advance()
