@@ -321,14 +321,19 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
     const bool llama = (c.arch == SD_ARCH_LLAMA);
     const int HqD = c.n_heads * c.head_dim;
     const bool w8 = cfg->weight_dtype == SD_FP8_E4M3;
-    const bool ok = gemm_skinny_covers(kSkinnyMaxT, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model, w8) &&
-                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, HqD, w8) &&
-                    gemm_skinny_covers(kSkinnyMaxT, llama ? c.d_ff : c.d_ff / 2, c.d_model, w8) &&
-                    gemm_skinny_covers(kSkinnyMaxT, c.d_model / 2, c.d_ff, w8) &&
-                    gemm_skinny_covers(kSkinnyMaxT, (c.vocab + 1) / 2, c.d_model, w8);
+    auto covers = [&](int T) {
+      return gemm_skinny_covers(T, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model, w8) &&
+             gemm_skinny_covers(T, c.d_model / 2, HqD, w8) && gemm_skinny_covers(T, llama ? c.d_ff : c.d_ff / 2, c.d_model, w8) &&
+             gemm_skinny_covers(T, c.d_model / 2, c.d_ff, w8) && gemm_skinny_covers(T, (c.vocab + 1) / 2, c.d_model, w8);
+    };
+    // the most tokens every matrix of the model can take in one pass: 128, 64 (x chunks of a pass must fit the LDS) ...
+    int cover_t = 0;
+    for (int T = kSkinnyMaxT; T >= 16 && !cover_t; T >>= 1)
+      if (covers(T)) cover_t = T;
+    const bool ok = cover_t != 0;
     const char* env = getenv("SPECDEC_MAX_PASS_TOKENS");  // testing knob: 9 forces the small-T kernel everywhere
-    int want = env ? atoi(env) : kSkinnyMaxT;
-    if (want > kSkinnyMaxT) want = kSkinnyMaxT;
+    int want = env ? atoi(env) : cover_t;
+    if (want > cover_t) want = cover_t;
     int kmax = c.d_model > HqD ? c.d_model : HqD;
     if (c.d_ff > kmax) kmax = c.d_ff;
     m->small_t = gemv_max_tokens(kmax);  // e.g. 5 for d_ff = 14336: x rows must fit the CU's LDS

@@ -40,10 +40,15 @@ static size_t skinny_smem(int T, int TG, int kc) {
 }
 
 // chunk width for (T, K, ksplit), or 0 when the shape is not covered
+static int skinny_tg(int T) {
+  const int tg = (T + 15) / 16;
+  return tg <= 4 ? tg : (tg <= 6 ? 6 : 8);
+}
+
 static int skinny_chunk(int T, int K, int ksplit, int kw, bool w8 = false) {
   const int ks = w8 ? 64 : 32;   // k covered by one 16-byte weight load
   if (K % ks != 0 || kw % ks != 0 || kw * ksplit != K) return 0;
-  const int TG = (T + 15) / 16;
+  const int TG = skinny_tg(T);
   int best = 0;
   for (int kc = ks * ksplit; kc <= kSkMaxKc; kc <<= 1) {
     if (K % kc != 0) break;
@@ -553,21 +558,26 @@ static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, 
 template <int EPI, bool W8>
 static int launch_skinny_w(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
   const int sc = 1 << sg.sc_shift;   // steps per wave per chunk: batches must not straddle a chunk boundary
+  const int tg = (a.T + 15) / 16;   // token groups: 1..4, then 6 and 8 (5 and 7 round up)
   if (sc == 1) {
-    switch ((a.T + 15) / 16) {
+    switch (tg) {
       case 1: return launch_skinny_one<EPI, 1, W8, 1>(a, sg, grid, smem, st);
       case 2: return launch_skinny_one<EPI, 2, W8, 1>(a, sg, grid, smem, st);
       case 3: return launch_skinny_one<EPI, 3, W8, 1>(a, sg, grid, smem, st);
-      default: return launch_skinny_one<EPI, 4, W8, 1>(a, sg, grid, smem, st);
+      case 4: return launch_skinny_one<EPI, 4, W8, 1>(a, sg, grid, smem, st);
+      case 5: case 6: return launch_skinny_one<EPI, 6, W8, 1>(a, sg, grid, smem, st);
+      default: return launch_skinny_one<EPI, 8, W8, 1>(a, sg, grid, smem, st);
     }
   }
-  switch ((a.T + 15) / 16) {
+  switch (tg) {
     case 1:
       if (sc % 4 == 0) return launch_skinny_one<EPI, 1, W8, 4>(a, sg, grid, smem, st);
       return launch_skinny_one<EPI, 1, W8, 2>(a, sg, grid, smem, st);
     case 2: return launch_skinny_one<EPI, 2, W8, 2>(a, sg, grid, smem, st);
     case 3: return launch_skinny_one<EPI, 3, W8, 2>(a, sg, grid, smem, st);
-    default: return launch_skinny_one<EPI, 4, W8, 2>(a, sg, grid, smem, st);
+    case 4: return launch_skinny_one<EPI, 4, W8, 2>(a, sg, grid, smem, st);
+    case 5: case 6: return launch_skinny_one<EPI, 6, W8, 2>(a, sg, grid, smem, st);
+    default: return launch_skinny_one<EPI, 8, W8, 2>(a, sg, grid, smem, st);
   }
 }
 
@@ -600,7 +610,7 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   const int sc = sg.kc / ((a.w8 ? 64 : 32) * q.ksplit);
   sg.sc_shift = 0;
   while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
-  const int TG = (a.T + 15) / 16;
+  const int TG = skinny_tg(a.T);
   // un-normalised, single-round shapes (out / down projections): operands straight to registers
   // (measured on the 3B shapes: ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads
   // touch 16 rows x 64 bytes per instruction)

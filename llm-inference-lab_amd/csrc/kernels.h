@@ -12,7 +12,7 @@ enum GemvPrologue { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };
 enum GemvEpilogue { EPI_QKV_ROPE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_ARGMAX = 4 };
 
 constexpr int kGemvMaxT = 9;     // tokens per launch of gemv.hip (K+1 for K = 8)
-constexpr int kSkinnyMaxT = 64;  // tokens per launch of gemm_skinny.hip (batched verify, chunked prefill)
+constexpr int kSkinnyMaxT = 128; // tokens per launch of gemm_skinny.hip (batched verify, chunked prefill)
 
 struct GemvArgs {
   // weights: bf16 [N][K] row-major

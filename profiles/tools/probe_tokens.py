@@ -15,7 +15,7 @@ hm = HipModel(mw, batch=1, l_max=64)
 st = torch.cuda.Stream()
 names = {1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head"}
 print("tokens | " + " | ".join(f"{names[w]:>16s}" for w in (1, 2, 3, 4)) + "   (us, TB/s)")
-for T in (1, 5, 9, 10, 16, 17, 24, 32, 40, 48, 64):
+for T in (1, 5, 9, 10, 16, 17, 24, 32, 40, 48, 64, 80, 96, 128):
     if T > hm.pass_tokens:
         break
     row = []

@@ -42,7 +42,7 @@ def test_fp8_forward_matches_oracle_over_dequantized_weights(name, L):
     want8, _ = OracleLM(fp8_ref.dequantized(mw), precision="bf16").forward(toks)
     want16, _ = OracleLM(mw, precision="bf16").forward(toks)
     hm = HipModel(mw.to("cuda"), batch=B, l_max=128, weight_dtype="fp8")
-    assert hm.pass_tokens == 64
+    assert hm.pass_tokens in (64, 128)
     ids, logits = hm.forward(toks.to(torch.int32).cuda(), torch.zeros(B, dtype=torch.int32, device="cuda"), 0, want_logits=True)
     got = logits.float().cpu()
     e8, gap = _rel_err(got, want8), _rel_err(want8, want16)
