@@ -226,8 +226,8 @@ typedef struct sd_model sd_model;
 int sd_model_create(const sd_model_config* cfg, sd_model** out);
 int sd_model_destroy(sd_model* m);
 
-/* Tokens one pass of sd_model_forward covers: 64 when every matrix of the model has a shape the
- * multi-token kernel (gemm_skinny.hip) handles, else 9. Larger B*M are tiled into passes. */
+/* Tokens one pass of sd_model_forward covers: 128 or 64 when every matrix of the model has a shape the
+ * multi-token kernel (gemm_skinny.hip) handles at that size, else 9 or fewer (x rows must fit the LDS). Larger B*M are tiled into passes. */
 int sd_model_pass_tokens(const sd_model* m);
 
 /* Scratch the forward needs (activations of one pass + argmax partials). */
