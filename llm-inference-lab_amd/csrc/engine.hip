@@ -443,7 +443,10 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * sizeof(unsigned long long)));
     SD_HIP_CHECK(hipMemset(dbg, 0, 256 * 8 * sizeof(unsigned long long)));
   }
+  // SPECDEC_PROBE_HOT=n: cycle over n layers only (n=1: the same matrix every launch, i.e. cache-resident weights)
+  const int hot = getenv("SPECDEC_PROBE_HOT") ? atoi(getenv("SPECDEC_PROBE_HOT")) : 0;
   auto launch = [&](int l) -> int {
+    if (hot > 0) l %= hot;
     const sd_layer_weights& w = m->layers[l % c.n_layers];
     GemvArgs g{};
     g.debug_ts = dbg;

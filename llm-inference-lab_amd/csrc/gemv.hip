@@ -141,6 +141,7 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, uint16_t* xs, int KP,
 template <int EPI, bool MASK, int TT, bool W8, int KB>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   constexpr int kBatch = KB;
+  pin_gemv_args<EPI, W8>(a);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
   const int KP = K + kXPad;

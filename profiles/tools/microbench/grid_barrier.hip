@@ -16,7 +16,7 @@ __global__ __launch_bounds__(1024) void barrier_kernel(unsigned* counter, float*
   float acc = 0.f;
   for (int p = 0; p < phases; ++p) {
     // a little "work": each WG writes a value every other WG reads after the barrier
-    if (payload && threadIdx.x < 64) data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc + p;
+    if (payload && threadIdx.x < 64) data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc * 0.5f + p;
     __syncthreads();
     if (threadIdx.x == 0) {
       if (MODE == 0) {
@@ -24,10 +24,36 @@ __global__ __launch_bounds__(1024) void barrier_kernel(unsigned* counter, float*
         const unsigned target = (p + 1) * nwg;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      } else {
+      } else if (MODE == 1) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (p + 1) * nwg;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      } else if (MODE == 3) {
+        // two levels: 16 group counters 1 KiB apart (different channels), the last arrival of a group bumps the top
+        unsigned* grp = counter + 256 * (1 + (blockIdx.x & 15));
+        const unsigned per = (nwg + 15) / 16;   // nwg is a multiple of 16 here
+        const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (p + 1) * per - 1) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * 16;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    if (MODE == 2) {
+      // no read-modify-write at all: every workgroup publishes its phase in its own slot, lane l of wave 0 of every
+      // workgroup polls slots 4l..4l+3 (one 1-KiB wave load covers 256 slots)
+      unsigned* flags = counter + 256;
+      if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned)(p + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < 64) {
+        const unsigned base = threadIdx.x * 4;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (base + j < nwg) ok = ok && (__hip_atomic_load(flags + base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(p + 1));
+          if (__all(ok)) break;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
     }
@@ -35,6 +61,43 @@ __global__ __launch_bounds__(1024) void barrier_kernel(unsigned* counter, float*
     if (payload) {
       const unsigned src = (blockIdx.x + 97) % nwg;   // another WG's (likely another XCD's) data
       if (threadIdx.x < 64) acc += data[(p & 1) * nwg * 64 + src * 64 + threadIdx.x];
+    }
+  }
+  if (payload && threadIdx.x < 64) data[2 * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+// MODE 4/5: no agent-scope fences at all (no L2 write-back / invalidate): the exchanged data itself moves with
+// agent-scope RELAXED atomics (stores write through to memory, loads bypass the XCD's L2); ordering comes from
+// waiting for the stores (workgroup-scope release = s_waitcnt) before the arrival and from the control dependency
+// on the poll. 4 = single counter, 5 = two-level counters.
+template <int MODE>
+__global__ __launch_bounds__(1024) void barrier_nofence_kernel(unsigned* counter, float* data, int phases, int payload) {
+  const unsigned nwg = gridDim.x;
+  float acc = 0.f;
+  for (int p = 0; p < phases; ++p) {
+    if (payload && threadIdx.x < 64)
+      __hip_atomic_store(&data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x], acc * 0.5f + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (MODE == 4) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * nwg;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      } else {
+        unsigned* grp = counter + 256 * (1 + (blockIdx.x & 15));
+        const unsigned per = (nwg + 15) / 16;
+        const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (p + 1) * per - 1) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * 16;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (payload) {
+      const unsigned src = (blockIdx.x + 97) % nwg;
+      if (threadIdx.x < 64) acc += __hip_atomic_load(&data[(p & 1) * nwg * 64 + src * 64 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (payload && threadIdx.x < 64) data[2 * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc;
@@ -48,24 +111,24 @@ int main() {
   const int ncu = prop.multiProcessorCount;
   printf("device %s, %d CUs\n", prop.name, ncu);
   unsigned* counter; float* data;
-  CK(hipMalloc(&counter, 4)); CK(hipMalloc(&data, 3 * ncu * 64 * 4));
+  CK(hipMalloc(&counter, 32768)); CK(hipMalloc(&data, 3 * ncu * 64 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int phases = 2000;
-  for (int mode = 0; mode < 2; ++mode)
+  for (int mode = 0; mode < 6; ++mode)
     for (int payload = 0; payload < 2; ++payload)
       for (int rep = 0; rep < 2; ++rep) {
-        CK(hipMemsetAsync(counter, 0, 4, st));
+        CK(hipMemsetAsync(counter, 0, 32768, st));
         CK(hipMemsetAsync(data, 0, 3 * ncu * 64 * 4, st));
         CK(hipEventRecord(e0, st));
         void* args[] = {&counter, &data, (void*)&phases, &payload};
         // cooperative launch: co-residency of all workgroups is guaranteed or the launch fails
-        if (mode == 0) CK(hipLaunchCooperativeKernel((void*)barrier_kernel<0>, dim3(ncu), dim3(1024), args, 0, st));
-        else CK(hipLaunchCooperativeKernel((void*)barrier_kernel<1>, dim3(ncu), dim3(1024), args, 0, st));
+        void* fn = mode == 0 ? (void*)barrier_kernel<0> : mode == 1 ? (void*)barrier_kernel<1> : mode == 2 ? (void*)barrier_kernel<2> : mode == 3 ? (void*)barrier_kernel<3> : mode == 4 ? (void*)barrier_nofence_kernel<4> : (void*)barrier_nofence_kernel<5>;
+        CK(hipLaunchCooperativeKernel(fn, dim3(ncu), dim3(1024), args, 0, st));
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep) printf("mode %d (%s) payload %d: %.3f us per barrier\n", mode, mode ? "sleep" : "spin", payload, ms * 1e3 / phases);
+        if (rep) printf("mode %d (%s) payload %d: %.3f us per barrier\n", mode, mode == 0 ? "spin" : mode == 1 ? "sleep" : mode == 2 ? "flag per workgroup" : mode == 3 ? "two-level counters" : mode == 4 ? "no fences, one counter" : "no fences, two-level counters", payload, ms * 1e3 / phases);
         if (payload && rep) {
           std::vector<float> h(ncu * 64);
           CK(hipMemcpy(h.data(), data + 2 * ncu * 64, ncu * 64 * 4, hipMemcpyDeviceToHost));
