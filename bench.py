@@ -248,6 +248,17 @@ def main():
         "step_roofline_frac": bytes_step / (ms_per_step / 1e3) / HBM_PEAK_BPS,
         "resyncs": sess.stats["resyncs"],
     }
+    # chained GEMV launches (csrc/gemv_chain.hip): opt-in (SPECDEC_CHAIN_PAIRS), off in the headline run; a barrier
+    # that ever timed out invalidates the run
+    chained = {}
+    for name in ("target", "draft"):
+        hm = sess.rt.get(name) if hasattr(sess.rt, "get") else None
+        if hm is not None and hasattr(hm, "chain_status"):
+            en, timed_out = hm.chain_status()
+            if timed_out:
+                raise RuntimeError(f"{name}: an in-kernel grid barrier of the chained GEMV launches timed out")
+            chained[name] = en
+    out["chained_launches"] = chained
     log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} tok/s")
     # ---- roofline of the dominant kernel, timed live with HIP events --------------------
     if not args.no_probe:

@@ -64,7 +64,10 @@ __device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int
 // ------------------------------------------------------------------------------
 // epilogues: one lane finishes token t of pair p (y0 = row r0, y1 = row r1)
 // ------------------------------------------------------------------------------
-template <int EPI>
+//   COH (EPI_RESID only): the new residual row is stored with an agent-scope relaxed atomic store (write-through to
+//   memory) so that the second phase of a chained launch (gemv_chain.hip) can read it on another XCD after the
+//   in-kernel grid barrier without an L2 write-back.
+template <int EPI, bool COH = false>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
                                          float y1, float& best_v, int& best_i, bool have_old = false,
                                          uint32_t old_pre = 0) {
@@ -116,7 +119,9 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
     const uint32_t old = have_old ? old_pre : *px;  // prefetched at kernel entry when possible
     const float n0 = __uint_as_float(old << 16) + y0;
     const float n1 = __uint_as_float(old & 0xffff0000u) + y1;
-    *px = static_cast<uint32_t>(float_to_bf16_bits(n0)) | (static_cast<uint32_t>(float_to_bf16_bits(n1)) << 16);
+    const uint32_t nv = static_cast<uint32_t>(float_to_bf16_bits(n0)) | (static_cast<uint32_t>(float_to_bf16_bits(n1)) << 16);
+    if constexpr (COH) __hip_atomic_store(px, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *px = nv;
   } else if constexpr (EPI == EPI_SWIGLU) {
     const float g = y0, u = y1;
     const float act = g / (1.0f + __expf(-g)) * u;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void barrier_nofence_kernel(unsigned* counter
   float acc = 0.f;
   for (int p = 0; p < phases; ++p) {
     if (payload && threadIdx.x < 64)
-      __hip_atomic_store(&data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x], acc * 0.5f + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&data[(p & 1) * nwg * 64 + blockIdx.x * 64 + threadIdx.x], (float)(p * 512 + (int)blockIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -97,10 +97,51 @@ __global__ __launch_bounds__(1024) void barrier_nofence_kernel(unsigned* counter
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (payload) {
       const unsigned src = (blockIdx.x + 97) % nwg;
-      if (threadIdx.x < 64) acc += __hip_atomic_load(&data[(p & 1) * nwg * 64 + src * 64 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < 64) {
+        const float v = __hip_atomic_load(&data[(p & 1) * nwg * 64 + src * 64 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != (float)(p * 512 + (int)src)) acc += 1.f;   // a stale or torn value
+      }
     }
   }
   if (payload && threadIdx.x < 64) data[2 * nwg * 64 + blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+// MODE 6: does the fence-free barrier overlap with a weight stream in flight? Per phase, waves 1..15 of every workgroup
+// issue NB independent 1-KiB loads (the GEMV's weight batch) BEFORE the barrier and consume them after it; wave 0 only
+// synchronises. with_barrier = 0 gives the pure stream time of the same loads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NB>
+__global__ __launch_bounds__(1024) void barrier_stream_kernel(unsigned* counter, const u32x4* big, size_t big_vec, unsigned* sink,
+                                                              int phases, int with_barrier) {
+  const unsigned nwg = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned acc = 0;
+  for (int p = 0; p < phases; ++p) {
+    u32x4 buf[NB];
+    if (wave != 0) {
+      size_t base = ((static_cast<size_t>(p) * nwg + blockIdx.x) * 15 + (wave - 1)) * NB * 64;
+      base %= (big_vec - NB * 64);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) buf[j] = __builtin_nontemporal_load(big + base + j * 64 + lane);
+    }
+    if (with_barrier) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (threadIdx.x == 0) {
+        unsigned* grp = counter + 256 * (1 + (blockIdx.x & 15));
+        const unsigned per = (nwg + 15) / 16;
+        const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (p + 1) * per - 1) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (p + 1) * 16;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      }
+    }
+    __syncthreads();
+    if (wave != 0) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc += buf[j][0] ^ buf[j][1] ^ buf[j][2] ^ buf[j][3];
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
 }
 
 __global__ void empty_kernel(float* d) { if (d == nullptr) *d = 0; }
@@ -114,7 +155,7 @@ int main() {
   CK(hipMalloc(&counter, 32768)); CK(hipMalloc(&data, 3 * ncu * 64 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int phases = 2000;
+  const int phases = 2000;   // p * 512 + wg stays exact in fp32
   for (int mode = 0; mode < 6; ++mode)
     for (int payload = 0; payload < 2; ++payload)
       for (int rep = 0; rep < 2; ++rep) {
@@ -134,9 +175,33 @@ int main() {
           CK(hipMemcpy(h.data(), data + 2 * ncu * 64, ncu * 64 * 4, hipMemcpyDeviceToHost));
           // every phase p adds (acc_src + p); all WGs symmetric -> acc identical everywhere
           bool same = true; for (int i = 1; i < ncu * 64; ++i) same &= (h[i] == h[0]);
-          printf("   payload check: %s (acc=%g)\n", same ? "consistent" : "MISMATCH", h[0]);
+          if (mode >= 4) { double bad = 0; for (int i = 0; i < ncu * 64; ++i) bad += h[i]; printf("   exact payload check: %g stale values in %d phases\n", bad, phases); }
+          else printf("   payload check: %s (acc=%g)\n", same ? "consistent" : "MISMATCH", h[0]);
         }
       }
+  {
+    const size_t big_bytes = 2ull << 30;
+    u32x4* big; unsigned* sink;
+    CK(hipMalloc(&big, big_bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(big, 1, big_bytes));
+    const size_t big_vec = big_bytes / 16;
+    const int ph = 400;
+    for (int nb = 6; nb <= 12; nb += 6)
+      for (int wb = 0; wb < 2; ++wb)
+        for (int rep = 0; rep < 2; ++rep) {
+          CK(hipMemsetAsync(counter, 0, 32768, st));
+          CK(hipEventRecord(e0, st));
+          void* args[] = {&counter, &big, (void*)&big_vec, &sink, (void*)&ph, &wb};
+          void* fn = nb == 6 ? (void*)barrier_stream_kernel<6> : (void*)barrier_stream_kernel<12>;
+          CK(hipLaunchCooperativeKernel(fn, dim3(ncu), dim3(1024), args, 0, st));
+          CK(hipEventRecord(e1, st));
+          CK(hipStreamSynchronize(st));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          const double mb = (double)ncu * 15 * nb * 1024 / 1e6;
+          if (rep) printf("stream of %d x 1 KiB per wave (%.1f MB per phase) %s: %.3f us per phase = %.2f TB/s\n", nb, mb,
+                          wb ? "+ fence-free barrier" : "alone (workgroup barrier only)", ms * 1e3 / ph, mb / (ms * 1e3 / ph));
+        }
+  }
   // floor of dependent kernel launches in a captured graph
   {
     hipGraph_t g; hipGraphExec_t ge;
