@@ -604,6 +604,8 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   a.tile_pairs = q.tile_pairs;
   a.ksplit = q.ksplit;
   a.kw = q.kw;
+  a.n_tiles_full = (q.ppw + q.tile_pairs - 1) / q.tile_pairs;
+  gemv_derive(a);   // the shared epilogues index with the derived shifts
   SkinnyGeom sg{};
   sg.kc = skinny_chunk(a.T, a.K, q.ksplit, q.kw, a.w8 != 0);
   SD_REQUIRE(sg.kc != 0, "gemm_skinny: shape T=%d K=%d (ksplit %d) is not covered", a.T, a.K, q.ksplit);

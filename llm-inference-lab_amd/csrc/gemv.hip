@@ -157,9 +157,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, kept in SGPRs
   const int g = lane >> 4, n = lane & 15;
   const int ksplit = a.ksplit;                 // power of two, <= 16
-  const int tiles_per_round = kGemvWaves / ksplit;
+  const int tiles_per_round = kGemvWaves >> a.ks_shift;
   const int kpart = wave & (ksplit - 1);
-  const int tslot = wave / ksplit;
+  const int tslot = wave >> a.ks_shift;
   const int kw = a.kw;                         // K span of one slice (multiple of 32)
   const int k_begin = kpart * kw;
   const int steps = W8 ? (kw >> 6) : (kw >> 5);  // loads per slice (an fp8 load covers 64 k)
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
   const int p_hi = min(p_lo + a.ppw, a.n_pairs);
   const int tile_pairs = a.tile_pairs;
-  const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;
-  const int rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
+  // (only the last workgroup can own less than ppw pairs: everyone else takes the host's tile count, no division)
+  const int n_tiles = (p_lo + a.ppw <= a.n_pairs) ? a.n_tiles_full : (p_hi - p_lo + tile_pairs - 1) / tile_pairs;
+  const int rounds = (n_tiles + tiles_per_round - 1) >> (4 - a.ks_shift);
 
   // lane's weight row inside a tile: rows 0..7 = first rows of the pairs, 8..15 = second
   // rows. Lanes without a pair alias the tile's first row (same address as lane 0: no
@@ -533,6 +534,8 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
   a.tile_pairs = q.tile_pairs;
   a.ksplit = q.ksplit;
   a.kw = q.kw;
+  a.n_tiles_full = (q.ppw + q.tile_pairs - 1) / q.tile_pairs;
+  gemv_derive(a);
   // MASK variant: slices that are not whole 32-k steps, or rows longer than the one-chunk-per-
   // thread register staging covers
   const bool mask = (a.kw * ksplit != a.K) || (a.K / 8 > kGemvThreads);

@@ -341,6 +341,8 @@ static bool prepare_phase(GemvArgs& a, size_t* smem) {
   a.tile_pairs = q.tile_pairs;
   a.ksplit = q.ksplit;
   a.kw = q.kw;
+  a.n_tiles_full = (q.ppw + q.tile_pairs - 1) / q.tile_pairs;
+  gemv_derive(a);
   if (a.kw * q.ksplit != a.K || a.K / 8 > kGemvThreads || a.K % 8 != 0 || a.x_stride % 8 != 0) return false;   // gemv.hip's MASK shapes
   size_t s = chain_smem(a.T, a.K, false);
   a.alias_part = 0;

@@ -36,11 +36,12 @@ template <int EPI, bool W8>
 __device__ __forceinline__ void pin_gemv_args(const GemvArgs& a) {
   SD_PIN("s"(a.W), "s"(a.K), "s"(a.T), "s"(a.kw), "s"(a.ppw), "s"(a.tile_pairs), "s"(a.ksplit), "s"(a.alias_part),
          "s"(a.debug_ts), "s"(a.packed), "s"(a.n_pairs), "s"(a.x), "s"(a.x_stride), "s"(a.x_row), "s"(a.prologue),
-         "s"(a.norm_w), "s"(a.norm_b), "s"(a.norm_eps), "s"(a.out), "s"(a.out_stride), "s"(a.M), "s"(a.bias), "s"(a.N));
+         "s"(a.norm_w), "s"(a.norm_b), "s"(a.norm_eps), "s"(a.out), "s"(a.out_stride), "s"(a.M), "s"(a.bias), "s"(a.N),
+         "s"(a.ks_shift), "s"(a.n_tiles_full), "s"(a.m_magic));
   if constexpr (W8) SD_PIN("s"(a.w_scale));
   if constexpr (EPI == EPI_QKV_ROPE)
     SD_PIN("s"(a.head_dim), "s"(a.n_q_heads), "s"(a.n_kv_heads), "s"(a.pos_base), "s"(a.pos_off), "s"(a.rope_cos),
-           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max));
+           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max), "s"(a.half_shift));
   if constexpr (EPI == EPI_ARGMAX) SD_PIN("s"(a.out_dtype), "s"(a.part_val), "s"(a.part_idx));
 }
 
@@ -49,7 +50,7 @@ template <int EPI>
 __device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int& r1) {
   if constexpr (EPI == EPI_QKV_ROPE) {
     const int half = a.head_dim >> 1;
-    const int h = p / half, i = p - h * half;
+    const int h = (a.half_shift >= 0) ? (p >> a.half_shift) : p / half, i = p - h * half;
     r0 = h * a.head_dim + i;
     r1 = r0 + half;
   } else if constexpr (EPI == EPI_SWIGLU) {
@@ -71,7 +72,7 @@ template <int EPI, bool COH = false>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
                                          float y1, float& best_v, int& best_i, bool have_old = false,
                                          uint32_t old_pre = 0) {
-  const int b = t / a.M, m = t - b * a.M;
+  const int b = static_cast<int>((static_cast<unsigned>(t) * a.m_magic) >> 16), m = t - b * a.M;   // t / M (gemv_derive)
   if constexpr (EPI == EPI_QKV_ROPE) {
     if (a.bias) {
       const uint16_t* bs = static_cast<const uint16_t*>(a.bias);
@@ -79,7 +80,7 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       y1 += bf16_bits_to_float(bs[r1]);
     }
     const int D = a.head_dim, half = D >> 1;
-    const int h = p / half, i = p - h * half;
+    const int h = (a.half_shift >= 0) ? (p >> a.half_shift) : p / half, i = p - h * half;
     const int pos = a.pos_base[b] + a.pos_off + m;
     float o0 = y0, o1 = y1;
     if (a.rope_cos && h < a.n_q_heads + a.n_kv_heads && pos >= 0 && pos < a.max_pos) {

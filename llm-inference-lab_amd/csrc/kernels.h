@@ -25,6 +25,12 @@ struct GemvArgs {
   int tile_pairs;    // pairs per tile, <= 8 (set by launch_gemv)
   int ksplit;        // K slices per tile, power of two <= 16 (set by launch_gemv)
   int alias_part;    // partial sums alias the staged x rows (set by launch_gemv)
+  // derived by the launchers (gemv_derive): the kernels' index arithmetic without runtime integer divisions — a
+  // division is ~25 instructions with a transcendental, and five of them sat between wave entry and the first weight load
+  int ks_shift;      // log2(ksplit)
+  int n_tiles_full;  // tiles of a workgroup that owns a full share of ppw pairs
+  int half_shift;    // log2(head_dim / 2), or -1 when head_dim / 2 is not a power of two (division fallback)
+  unsigned m_magic;  // ceil(65536 / M): t / M == (t * m_magic) >> 16 for t < 65536 / M... (exact for t < 512)
   unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
   int packed;                    // W is in the packed tile-stream order of csrc/pack.hip
   int w8;                        // W holds OCP fp8 e4m3 values (packed only); acc of row r is scaled by w_scale[r]
@@ -59,6 +65,19 @@ struct GemvArgs {
   int* part_idx;
 };
 
+
+// fields of GemvArgs every launcher derives from the caller's (idempotent)
+inline void gemv_derive(GemvArgs& a) {
+  const int half = a.head_dim >> 1;
+  a.half_shift = -1;
+  if (half > 0 && (half & (half - 1)) == 0)
+    for (int s = 0; s < 31; ++s)
+      if ((1 << s) == half) a.half_shift = s;
+  const int M = a.M > 0 ? a.M : 1;
+  a.m_magic = static_cast<unsigned>((65536 + M - 1) / M);
+  a.ks_shift = 0;
+  while ((1 << a.ks_shift) < a.ksplit) ++a.ks_shift;
+}
 
 // work split of one matrix over the chip (shared by the launcher and the weight packer)
 struct GemvGeom {
