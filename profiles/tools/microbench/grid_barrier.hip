@@ -144,6 +144,44 @@ __global__ __launch_bounds__(1024) void barrier_stream_kernel(unsigned* counter,
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// MODE 7: a PACED stream — every wave keeps only W 1-KiB loads in flight (rolling window, straight-line code so hipcc
+// emits counted vmcnt waits) while wave 0 runs the fence-free barrier concurrently. Does a shallow queue (chip-wide
+// 256 x 15 x W KiB in flight) still reach the stream's bandwidth, and what does the barrier cost next to it?
+template <int NB, int W>
+__global__ __launch_bounds__(1024) void barrier_paced_kernel(unsigned* counter, const u32x4* big, size_t big_vec, unsigned* sink,
+                                                             unsigned long long* lat, int phases, int with_barrier) {
+  const unsigned nwg = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned acc = 0;
+  unsigned long long lat_sum = 0;
+  for (int p = 0; p < phases; ++p) {
+    if (wave != 0) {
+      size_t base = ((static_cast<size_t>(p) * nwg + blockIdx.x) * 15 + (wave - 1)) * NB * 64;
+      base %= (big_vec - NB * 64);
+      u32x4 buf[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) buf[j] = __builtin_nontemporal_load(big + base + j * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        acc += buf[j % W][0] ^ buf[j % W][1] ^ buf[j % W][2] ^ buf[j % W][3];
+        if (j + W < NB) buf[j % W] = __builtin_nontemporal_load(big + base + (j + W) * 64 + lane);
+      }
+    } else if (with_barrier && threadIdx.x == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned* grp = counter + 256 * (1 + (blockIdx.x & 15));
+      const unsigned per = (nwg + 15) / 16;
+      const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (p + 1) * per - 1) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (p + 1) * 16;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      lat_sum += __builtin_amdgcn_s_memrealtime() - t0;
+    }
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+  if (with_barrier && threadIdx.x == 0) lat[blockIdx.x] = lat_sum;
+}
+
 __global__ void empty_kernel(float* d) { if (d == nullptr) *d = 0; }
 
 int main() {
@@ -200,6 +238,50 @@ int main() {
           const double mb = (double)ncu * 15 * nb * 1024 / 1e6;
           if (rep) printf("stream of %d x 1 KiB per wave (%.1f MB per phase) %s: %.3f us per phase = %.2f TB/s\n", nb, mb,
                           wb ? "+ fence-free barrier" : "alone (workgroup barrier only)", ms * 1e3 / ph, mb / (ms * 1e3 / ph));
+        }
+  }
+  {
+    const size_t big_bytes = 2ull << 30;
+    u32x4* big; unsigned* sink; unsigned long long* lat;
+    CK(hipMalloc(&big, big_bytes)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&lat, ncu * 8));
+    CK(hipMemset(big, 1, big_bytes));
+    const size_t big_vec = big_bytes / 16;
+    const int ph = 400;
+    const int Ws[6] = {1, 2, 3, 4, 6, 12};
+    for (int wi = 0; wi < 6; ++wi)
+      for (int wb = 0; wb < 2; ++wb)
+        for (int rep = 0; rep < 2; ++rep) {
+          CK(hipMemsetAsync(counter, 0, 32768, st));
+          CK(hipMemsetAsync(lat, 0, ncu * 8, st));
+          CK(hipEventRecord(e0, st));
+          void* args[] = {&counter, &big, (void*)&big_vec, &sink, &lat, (void*)&ph, &wb};
+          void* fn = nullptr;
+          switch (Ws[wi]) {
+            case 1: fn = (void*)barrier_paced_kernel<12, 1>; break;
+            case 2: fn = (void*)barrier_paced_kernel<12, 2>; break;
+            case 3: fn = (void*)barrier_paced_kernel<12, 3>; break;
+            case 4: fn = (void*)barrier_paced_kernel<12, 4>; break;
+            case 6: fn = (void*)barrier_paced_kernel<12, 6>; break;
+            default: fn = (void*)barrier_paced_kernel<12, 12>; break;
+          }
+          CK(hipLaunchCooperativeKernel(fn, dim3(ncu), dim3(1024), args, 0, st));
+          CK(hipEventRecord(e1, st));
+          CK(hipStreamSynchronize(st));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          const double mb = (double)ncu * 15 * 12 * 1024 / 1e6;
+          if (rep) {
+            double bl = 0;
+            if (wb) {
+              std::vector<unsigned long long> h(ncu);
+              CK(hipMemcpy(h.data(), lat, ncu * 8, hipMemcpyDeviceToHost));
+              for (int i = 0; i < ncu; ++i) bl += (double)h[i];
+              bl = bl / ncu / ph / 100.0;   // 100 MHz ticks -> us
+            }
+            printf("paced stream, window %2d loads per wave (%.1f MB in flight chip-wide, %.1f MB per phase) %s: %.3f us per phase = %.2f TB/s",
+                   Ws[wi], (double)ncu * 15 * Ws[wi] * 1024 / 1e6, mb, wb ? "+ concurrent barrier" : "alone", ms * 1e3 / ph, mb / (ms * 1e3 / ph));
+            if (wb) printf(", barrier latency seen by wave 0: %.2f us", bl);
+            printf("\n");
+          }
         }
   }
   // floor of dependent kernel launches in a captured graph
