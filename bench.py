@@ -278,7 +278,7 @@ def main():
         if os.path.exists(pmc) and B * (K + 1) == 5 and wd == "bf16" and args.target == "llama-3.2-3b":
             with open(pmc) as f:
                 tj = json.load(f)
-                t = tj.get("gemv_mfma_kernel<2, false, 5, false>") or tj.get("gemv_mfma_kernel<2, false, 5>")
+                t = next((v for k, v in tj.items() if k.startswith("gemv_mfma_kernel<2, false, 5, false")), None)
             if t:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc passes of bench.py)"
