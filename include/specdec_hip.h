@@ -309,6 +309,20 @@ int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperature, int to
                             uint64_t seed, void* logits_buf, size_t logits_bytes,
                             uint32_t* draw_counters, const int32_t* stream_ids);
 
+/* EAGLE-lite drafting (the reference's _run_eagle_hf, src/specdec/core/pipeline.py:765-889, under greedy decoding), for
+ * a loop created with draft = NULL: every step runs a 1-token target forward for the residual row of the last token,
+ * h_t = final_norm(row); extrapolates K hidden rows h_1 = h_t + alpha (h_t - E), h_2 = h_1 + alpha (h_1 - h_t), ...
+ * (E = the last extrapolated row of the previous step of that batch row; on a row's first step h_t stands in for it;
+ * every operation rounds to bf16 as the reference's bf16 tensors do); scores all K rows with ONE lm_head launch
+ * (d_i = argmax lm_head(h_i)); then verifies (last, d_1..d_K) as usual. K = min(k, eagle.max_draft) is the caller's
+ * choice at sd_specdec_create. `workspace` (sd_specdec_eagle_bytes, caller-owned device memory, must outlive the loop)
+ * holds the per-row state (at offsets independent of K: loops of different K may share one workspace sized for the
+ * largest) and the extrapolated rows. Call before the first step, then sd_specdec_reset_eagle, which forgets the state
+ * of all rows (start of a new set of sequences; enqueued on `stream`) — set_eagle itself does not touch the state. */
+size_t sd_specdec_eagle_bytes(int B, int K, int d_model);
+int sd_specdec_set_eagle(sd_specdec* s, float alpha, void* workspace, size_t workspace_bytes);
+int sd_specdec_reset_eagle(sd_specdec* s, void* stream);
+
 /* Persistent multi-head (Medusa) drafting for a loop created with draft = NULL: K heads, each a
  * vocabulary-sized matrix [V][d_model] packed by sd_pack_head in `weight_dtype`. After the accept scan of a step
  * the heads read the target's final-norm input row of the position that produced the last emitted token and

@@ -684,6 +684,12 @@ struct sd_specdec {
   std::vector<const void*> heads;
   std::vector<const float*> head_scales;
   int32_t* head_rows = nullptr;    // [B] device: row of the target's residual stream each head reads
+  // EAGLE-lite (sd_specdec_set_eagle): extrapolated hidden rows instead of a draft model; caller-owned workspace
+  int eagle = 0;
+  float eagle_alpha = 0.7f;
+  uint16_t* eagle_H = nullptr;     // [B*K][d]
+  uint16_t* eagle_prev = nullptr;  // [B][d] last extrapolated row of the previous step
+  int32_t* eagle_has = nullptr;    // [B]
 };
 
 namespace sd {
@@ -753,7 +759,37 @@ static int enqueue_medusa_heads(sd_specdec* s, hipStream_t st) {
 static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   const int B = s->B, K = s->K;
   const bool two = (st_d != st_t) && s->draft;
-  if (!s->draft && s->heads.empty()) {
+  if (!s->draft && s->eagle) {
+    // EAGLE-lite: residual row of `last` (1-token forward, head skipped) -> K extrapolated rows -> one lm_head launch
+    sd_model* m = s->target;
+    const sd_model_config& c = m->cfg;
+    if (int rc = model_forward(m, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, 1, nullptr, 2, nullptr, SD_BF16, 1, st_t)) return rc;
+    if (int rc = launch_eagle_extrapolate(m->x, s->eagle_H, s->eagle_prev, s->eagle_has, c.final_norm_w, c.final_norm_b, c.norm_eps,
+                                          s->eagle_alpha, c.d_model, B, K, c.arch == SD_ARCH_LLAMA ? 1 : 0, st_t))
+      return rc;
+    GemvArgs h{};
+    h.packed = m->is_packed();
+    h.w8 = m->w8();
+    h.w_scale = m->scale(4 * c.n_layers);
+    h.W = m->mat(4 * c.n_layers, c.lm_head);
+    h.N = c.vocab;
+    h.K = c.d_model;
+    h.n_pairs = (c.vocab + 1) / 2;
+    h.x = s->eagle_H;
+    h.x_stride = c.d_model;
+    h.T = B * K;
+    h.M = K;
+    h.prologue = PRO_NONE;     // the rows are final-norm outputs already
+    h.out = nullptr;
+    h.out_dtype = SD_BF16;
+    h.part_val = m->part_val;
+    h.part_idx = m->part_idx;
+    int ppw = 1;
+    const int grid = gemv_grid(h, &ppw);
+    if (int rc = launch_gemv(h, EPI_ARGMAX, st_t)) return rc;
+    if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, B * K, grid, K, K + 1, s->st.verify_tok + 1, st_t)) return rc;
+    if (int rc = launch_medusa_commit(s->st, st_t)) return rc;
+  } else if (!s->draft && s->heads.empty()) {
     // self-draft (Medusa-lite, tied heads): the target's own next token, K times
     if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, 1, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_t))
       return rc;
@@ -920,6 +956,40 @@ extern "C" int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperat
   s->logits = logits_buf;
   s->draw = draw_counters;
   s->stream_id = stream_ids;
+  return 0;
+}
+
+extern "C" size_t sd_specdec_eagle_bytes(int B, int K, int d_model) {
+  if (B <= 0 || K <= 0 || d_model <= 0) return 0;
+  return (static_cast<size_t>(B) * K * d_model + static_cast<size_t>(B) * d_model) * 2 + static_cast<size_t>(B) * 4 + 1024;
+}
+
+// workspace layout: [state rows B x d bf16][has_prev B x int32][extrapolated rows B*K x d bf16] — the state sits at
+// offsets that do not depend on K, so loops of different K over the same workspace (adaptive K) share it
+extern "C" int sd_specdec_set_eagle(sd_specdec* s, float alpha, void* workspace, size_t workspace_bytes_) {
+  clear_error();
+  SD_REQUIRE(s && workspace, "specdec_set_eagle: NULL argument");
+  SD_REQUIRE(!s->draft, "specdec_set_eagle: the loop was created with a draft model (pass draft = NULL)");
+  SD_REQUIRE(s->heads.empty(), "specdec_set_eagle: the loop already has Medusa heads");
+  const int d = s->target->cfg.d_model;
+  SD_REQUIRE(workspace_bytes_ >= sd_specdec_eagle_bytes(s->B, s->K, d), "specdec_set_eagle: workspace too small");
+  SD_REQUIRE(s->B * s->K <= s->target->max_t, "specdec_set_eagle: B*K = %d rows exceed one lm_head pass (%d)", s->B * s->K, s->target->max_t);
+  SD_REQUIRE(!s->exec, "specdec_set_eagle: call before the first captured step");
+  char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  s->eagle_prev = reinterpret_cast<uint16_t*>(p);
+  p += (static_cast<size_t>(s->B) * d * 2 + 255) & ~static_cast<size_t>(255);
+  s->eagle_has = reinterpret_cast<int32_t*>(p);
+  p += (static_cast<size_t>(s->B) * 4 + 255) & ~static_cast<size_t>(255);
+  s->eagle_H = reinterpret_cast<uint16_t*>(p);
+  s->eagle_alpha = alpha;
+  s->eagle = 1;
+  return 0;
+}
+
+extern "C" int sd_specdec_reset_eagle(sd_specdec* s, void* stream) {
+  clear_error();
+  SD_REQUIRE(s && s->eagle, "specdec_reset_eagle: EAGLE mode is not set");
+  SD_HIP_CHECK(hipMemsetAsync(s->eagle_has, 0, static_cast<size_t>(s->B) * 4, static_cast<hipStream_t>(stream)));
   return 0;
 }
 

@@ -116,6 +116,86 @@ __global__ void medusa_commit_kernel(SpecState s) {
   for (int i = 0; i < s.K; ++i) s.draft_tok[b * s.K + i] = s.verify_tok[b * (s.K + 1) + i + 1];
 }
 
+// EAGLE-lite (the reference's _run_eagle_hf, pipeline.py:765-889, greedy): the draft is read off EXTRAPOLATED hidden
+// states of the target, no draft model. h_t = final_norm(residual row of the last token); with the state the previous
+// step left behind (its LAST extrapolated row; none on a row's first step, where h_t stands in for it)
+//   h_1 = h_t + alpha (h_t - E),  h_2 = h_1 + alpha (h_1 - h_t), ...   d_i = argmax lm_head(h_i)
+// Every operation rounds to bf16 as the bf16 tensors of the reference do (difference, alpha * difference in fp32 with
+// alpha as a float, sum). The h_i do not depend on the tokens, so all K rows are produced here and ONE lm_head launch
+// scores them. One workgroup per batch row; the row's state E <- h_K.
+struct EagleArgs {
+  const uint16_t* x;   // [B][d] residual rows (forward with skip_head)
+  uint16_t* H;         // [B*K][d] extrapolated rows
+  uint16_t* prev;      // [B][d] state E
+  int32_t* has_prev;   // [B]
+  const uint16_t* norm_w;
+  const uint16_t* norm_b;
+  float eps, alpha;
+  int d, K, rms;
+};
+
+__global__ __launch_bounds__(256) void eagle_extrapolate_kernel(EagleArgs a) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint16_t* x = a.x + static_cast<size_t>(b) * a.d;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < a.d; i += 256) {
+    const float v = bf16_bits_to_float(x[i]);
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_reduce_sum(s1);
+  s2 = wave_reduce_sum(s2);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+  __syncthreads();
+  const float sum = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const float sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const float invd = 1.0f / static_cast<float>(a.d);
+  const float mean = sum * invd;
+  const float rs = a.rms ? rsqrtf(sq * invd + a.eps) : rsqrtf(fmaxf(sq * invd - mean * mean, 0.f) + a.eps);
+  const bool has = a.has_prev[b] != 0;
+  uint16_t* prev = a.prev + static_cast<size_t>(b) * a.d;
+  for (int i = tid; i < a.d; i += 256) {
+    const float v = bf16_bits_to_float(x[i]);
+    float ht;
+    if (a.rms) {   // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
+      ht = bf16_bits_to_float(float_to_bf16_bits(bf16_bits_to_float(float_to_bf16_bits(v * rs)) * bf16_bits_to_float(a.norm_w[i])));
+    } else {       // LayerNorm in fp32, rounded once
+      ht = bf16_bits_to_float(float_to_bf16_bits((v - mean) * rs * bf16_bits_to_float(a.norm_w[i]) + bf16_bits_to_float(a.norm_b[i])));
+    }
+    float prv = has ? bf16_bits_to_float(prev[i]) : ht, cur = ht;
+    for (int k = 0; k < a.K; ++k) {
+      const float diff = bf16_bits_to_float(float_to_bf16_bits(cur - prv));
+      const float sc = bf16_bits_to_float(float_to_bf16_bits(a.alpha * diff));
+      const uint16_t nb = float_to_bf16_bits(cur + sc);
+      a.H[(static_cast<size_t>(b) * a.K + k) * a.d + i] = nb;
+      prv = cur;
+      cur = bf16_bits_to_float(nb);
+    }
+    prev[i] = float_to_bf16_bits(cur);
+  }
+  if (tid == 0) a.has_prev[b] = 1;
+}
+
+int launch_eagle_extrapolate(const void* x, void* H, void* prev, int32_t* has_prev, const void* norm_w, const void* norm_b,
+                             float eps, float alpha, int d, int B, int K, int rms, hipStream_t st) {
+  EagleArgs a{};
+  a.x = static_cast<const uint16_t*>(x);
+  a.H = static_cast<uint16_t*>(H);
+  a.prev = static_cast<uint16_t*>(prev);
+  a.has_prev = has_prev;
+  a.norm_w = static_cast<const uint16_t*>(norm_w);
+  a.norm_b = static_cast<const uint16_t*>(norm_b);
+  a.eps = eps;
+  a.alpha = alpha;
+  a.d = d;
+  a.K = K;
+  a.rms = rms;
+  hipLaunchKernelGGL(eagle_extrapolate_kernel, dim3(B), dim3(256), 0, st, a);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_medusa_rows(const SpecState& s, int32_t* row_idx, hipStream_t st) {
   hipLaunchKernelGGL(medusa_rows_kernel, dim3((s.B + 63) / 64), dim3(64), 0, st, s, row_idx);
   SD_LAUNCH_CHECK();

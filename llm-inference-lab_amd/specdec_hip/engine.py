@@ -250,6 +250,22 @@ class HipSpecDec:
             arr = (ctypes.c_void_p * K)(*[b.data_ptr() for b in self._heads_packed])
             _abi.check(self.lib.sd_specdec_set_medusa(self.handle, K, arr, wd), "sd_specdec_set_medusa")
 
+    def set_eagle(self, alpha: float = 0.7, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """EAGLE-lite drafting for a loop created with draft=None (sd_specdec_set_eagle): K extrapolated hidden rows
+        per step, scored by one lm_head launch. `workspace` (uint8, shared between loops of different K so that the
+        per-row state survives a change of K) is allocated for K = 8 when not given; returns it."""
+        d = self.target.cfg.d_model
+        if workspace is None:
+            workspace = torch.zeros(int(self.lib.sd_specdec_eagle_bytes(self.B, 8, d)), dtype=torch.uint8, device=self.device)
+        self._eagle_ws = workspace
+        _abi.check(self.lib.sd_specdec_set_eagle(self.handle, ctypes.c_float(alpha), workspace.data_ptr(), workspace.numel()),
+                   "sd_specdec_set_eagle")
+        return workspace
+
+    def reset_eagle(self):
+        """Forget the extrapolation state of every row (start of new sequences); ordered on the loop's target stream."""
+        _abi.check(self.lib.sd_specdec_reset_eagle(self.handle, self.stream_t.cuda_stream), "sd_specdec_reset_eagle")
+
     def set_sampling(self, enable: bool, temperature: float = 1.0, top_k: Optional[int] = None,
                      top_p: Optional[float] = None, seed: int = 0, stream_ids: Optional[Sequence[int]] = None,
                      draw_counts: Optional[Sequence[int]] = None):

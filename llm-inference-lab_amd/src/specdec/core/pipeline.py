@@ -59,6 +59,7 @@ _DEFAULTS: Dict[str, Any] = {
     "verbose": False,
     "draft_mode": "vanilla",
     "medusa": {"enabled": False, "num_heads": 2, "head_init": "tie", "temperature": 0.7, "top_p": 1.0},
+    "eagle": {"enabled": False, "alpha": 0.7, "max_draft": 2},
 }
 
 
@@ -110,8 +111,13 @@ class SpeculativePipeline:
             # (pipeline.py:689-705), which has no reproducible restatement; `head_init: random` is refused.
             if self.config.get("medusa", {}).get("head_init", "tie") not in ("tie", "copy"):
                 raise NotImplementedError("draft_mode='medusa' needs medusa.head_init 'tie' or 'copy' (random heads are not restated)")
+        elif mode == "eagle":
+            # EAGLE-lite as the reference's HF path defines it (_run_eagle_hf, pipeline.py:765-889): draft tokens are the
+            # argmax of the lm_head over hidden states extrapolated from the target's last two states, min(k, max_draft)
+            # of them per step; generate() only, no draft model (sd_specdec_set_eagle).
+            pass
         elif mode != "vanilla":
-            raise NotImplementedError(f"draft_mode={mode!r}: 'vanilla' and 'medusa' drafting are on the HIP path")
+            raise NotImplementedError(f"draft_mode={mode!r}: 'vanilla', 'medusa' and 'eagle' drafting are on the HIP path")
         if not torch.cuda.is_available():
             raise RuntimeError("SpeculativePipeline needs a GPU (PyTorch-ROCm device 'cuda'); there is no CPU path")
         self.device = "cuda"
@@ -123,7 +129,7 @@ class SpeculativePipeline:
         ensure_deterministic(int(self.config.get("seed") or 1234))
 
         self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
-        no_draft = mode == "medusa" and draft_lm is None and self.config.get("draft_model") in (None, "", "none", "NONE")
+        no_draft = mode in ("medusa", "eagle") and draft_lm is None and self.config.get("draft_model") in (None, "", "none", "NONE")
         self.draft_lm = draft_lm if (draft_lm is not None or no_draft) else create_hip_lm(self.config["draft_model"])
         for who, lm in (("base", self.base_lm), ("draft", self.draft_lm)):
             if lm is None and who == "draft":
@@ -174,7 +180,19 @@ class SpeculativePipeline:
                 if self.medusa_heads.n_heads != k:
                     raise ValueError(f"{self.medusa_heads.n_heads} medusa heads but K={k}")
                 loop.set_medusa(self.medusa_heads.weights, self.base_lm.weight_dtype)
+            elif self_draft and self._eagle():
+                # one state workspace per runtime: loops of different K continue the same extrapolation state
+                rt["eagle_ws"] = loop.set_eagle(float(self.config.get("eagle", {}).get("alpha", 0.7)), rt.get("eagle_ws"))
         return rt, loop
+
+    def _eagle(self) -> bool:
+        return self.config.get("draft_mode") == "eagle"
+
+    def _effective_k(self, k: int, self_draft: bool) -> int:
+        """EAGLE-lite proposes min(k, eagle.max_draft) tokens per step (pipeline.py:818 of the reference)."""
+        if self_draft and self._eagle():
+            return max(1, min(int(k), int(self.config.get("eagle", {}).get("max_draft", 2))))
+        return int(k)
 
     def _encode(self, prompt: PromptLike) -> List[int]:
         if isinstance(prompt, str):
@@ -330,7 +348,7 @@ class SpeculativePipeline:
         # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
         # drafts with the draft model
         rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
-                                self_draft=self.config.get("draft_mode") == "medusa")
+                                self_draft=self.config.get("draft_mode") in ("medusa", "eagle"))
         r = rows[0]
         total_ms = (time.time() - t_begin) * 1e3
         self.metrics = {"total_proposed": r.proposed, "total_accepted": r.accepted, "total_steps": st["steps"],
@@ -457,7 +475,7 @@ class SpeculativePipeline:
             "cuda_mem_peak_mb": float(torch.cuda.max_memory_allocated() / 1024 / 1024),
             "policy": self.policy.get_info(), "controller": self.controller.get_info(),
             "impl": "hip", "device": self.device, "dtype": "bfloat16", "amp_enabled": False,
-            "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name if self.draft_lm is not None else "none (medusa heads tied to the base lm_head)",
+            "base_model": self.base_lm.model_name, "draft_model": self.draft_lm.model_name if self.draft_lm is not None else "none (self-drafting from the base model: medusa heads tied to its lm_head / eagle extrapolation)",
             "draft_mode": self.config.get("draft_mode", "vanilla"),
         }
 
@@ -493,7 +511,7 @@ class DecodeSession:
         ctl = pipe.controller
         k_max = getattr(ctl, "max_k", None) or getattr(ctl, "k", 4)
         self.need = max(len(r.seq) for r in self.rows) + max_tokens + 2 * int(k_max) + 8
-        self.k = int(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}))
+        self.k = pipe._effective_k(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}), self_draft)
         self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode, self.self_draft)
         # positions a row may use: the cache rows and both models' position tables
         self.pos_limit = min(self.rt["l_max"], pipe.base_lm.config.max_pos,
@@ -506,14 +524,17 @@ class DecodeSession:
         for b, r in enumerate(self.rows):
             pipe._set_row(self.loop, b, r)
         self._apply_sampling()
+        self._stateful_draft = self_draft and (pipe.medusa_heads is not None or pipe._eagle())
+        if self_draft and pipe._eagle():
+            self.loop.reset_eagle()   # the reference keeps the state on the pipeline object, across generate() calls even; here a run starts clean
         self.stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
         self.step = 0
         from ..policies.controllers import FixedKController
 
-        # (persistent Medusa heads: a void step would replace the next proposals with ones derived from stale state —
-        # harmless for the tokens, but the counters would no longer be those of the in-order loop)
+        # (persistent Medusa heads / EAGLE-lite: a void step would replace the next proposals with ones derived from stale
+        # state — harmless for the tokens, but the counters would no longer be those of the in-order loop)
         self._early = (isinstance(ctl, FixedKController) and sampling is None
-                       and not (self_draft and pipe.medusa_heads is not None)
+                       and not self._stateful_draft
                        and os.environ.get("SPECDEC_EARLY_LAUNCH", "1") != "0")
         self._depth = 2 if self._early else 1
         if os.environ.get("SPECDEC_LAUNCH_DEPTH"):
@@ -608,6 +629,7 @@ class DecodeSession:
             k_new = int(pipe.controller.get_k(step, ctx))
             if k_new <= 0:
                 return False
+            k_new = pipe._effective_k(k_new, self.self_draft)
             if k_new != self.k:  # adaptive K: another captured step over the same caches
                 self.loop.sync()
                 self._repair_rows()

@@ -153,7 +153,7 @@ class OraclePipeline:
     same tokens faster (used by the parity tests)."""
 
     def __init__(self, base: OracleLM, draft: Optional[OracleLM], k: int = 4, eos_token_id: Optional[int] = None,
-                 reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None):
+                 reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None, eagle_alpha: float = 0.7):
         """draft_mode "medusa_tied": the reference's MedusaDraftor (src/specdec/modes/medusa.py:71-186) with
         head_init tie/copy under greedy decoding — every head is the base lm_head and head 0 is evaluated on the
         same last hidden state for each of the K proposals, so the draft is K copies of the base model's own
@@ -164,6 +164,11 @@ class OraclePipeline:
         # are argmax head_i(final_norm(h)) with h = the base model's residual row at the position that produced the
         # last emitted token in the PREVIOUS step's verify pass; a row's first step proposes zeros
         self.medusa_heads = medusa_heads
+        # "eagle": the reference's _run_eagle_hf (pipeline.py:765-889) under greedy decoding; k = min(k, eagle.max_draft)
+        # is the caller's. State per row = the LAST extrapolated hidden row of the previous step (what
+        # `_eagle_last_hidden_states[:, -1:]` holds when the next call concatenates the new hidden state to it).
+        self.eagle_alpha = float(eagle_alpha)
+        self._eagle_state: Dict[int, torch.Tensor] = {}
         self._next_draft: Dict[int, List[int]] = {}
         self.eos = eos_token_id
         self.reprefill = reprefill
@@ -184,7 +189,9 @@ class OraclePipeline:
             h = self.base.last_hidden[0, len(seq) - 1 + a]
             self._next_draft[row] = self.base.head_tokens(h, self.medusa_heads)
             return draft, t, a
-        if self.draft_mode == "medusa_tied":
+        if self.draft_mode == "eagle":
+            draft = self._eagle_draft(ids, row, k)
+        elif self.draft_mode == "medusa_tied":
             t0, _ = self.base.generate_tokens(ids, 1, reprefill=self.reprefill)
             draft = [int(t0[0, 0])] * k
         else:
@@ -213,6 +220,29 @@ class OraclePipeline:
         a = longest_prefix(draft, t)
         return draft, t, a
 
+    def _eagle_draft(self, ids: torch.Tensor, row: int, k: int) -> List[int]:
+        """pipeline.py:786-858: h_t = last hidden state (after the final norm) of the last position; states = [E, h_t]
+        (first call: [h_t], where the fallback `h_next = current_hidden` and the then-equal pair make every proposal
+        lm_head(h_t)); h_next = h_t + alpha * (h_t - h_{t-1}) with the window sliding over the extrapolated rows;
+        token = argmax lm_head(h_next). In bf16 mode every tensor operation rounds, as the reference's bf16 tensors do
+        (alpha enters as a float32 scalar)."""
+        b = self.base
+        b.forward(ids)
+        x_last = b.last_hidden[0, -1]
+        h_t = b._norm(x_last.view(1, 1, -1), "nf", b.w.final_norm_w, b.w.final_norm_b).view(-1)
+        prv = self._eagle_state.get(row, h_t)
+        cur = h_t
+        head = b._m("lm_head", b.w.lm_head)
+        alpha = torch.tensor(self.eagle_alpha, dtype=torch.float32)
+        draft = []
+        for _ in range(k):
+            diff = b._r(cur - prv)
+            nxt = b._r(cur + b._r(alpha * diff))
+            draft.append(int(b._r(nxt.view(1, -1) @ head.t()).view(-1).argmax()))
+            prv, cur = cur, nxt
+        self._eagle_state[row] = cur
+        return draft
+
     def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int,
                        max_steps: Optional[int] = None, sampling: Optional[Dict] = None) -> List[Dict]:
         """`max_steps` (not in the reference) bounds a timing sample to a number of steps.
@@ -224,6 +254,7 @@ class OraclePipeline:
         rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
         self.trace = []
         self._next_draft = {}
+        self._eagle_state = {}
         t0 = time.time()
         step = 0
         while step < max_tokens and (max_steps is None or step < max_steps):   # :1984 bound is STEPS, not tokens
@@ -256,6 +287,7 @@ class OraclePipeline:
         r = RowState(seq=[int(x) for x in prompt])
         self.trace = []
         self._next_draft = {}
+        self._eagle_state = {}
         t0 = time.time()
         step = 0
         while len(r.generated) < max_tokens and step < 2 * max_tokens:   # :984-986

@@ -208,6 +208,57 @@ def gen_pipeline():
         json.dump(out, f, indent=1, default=str)
 
 
+def gen_pipeline_eagle():
+    """Traces of the REFERENCE pipeline with draft_mode="eagle" (its HF path, _run_eagle_hf, pipeline.py:765-889) on the
+    G8 target models: generate(), CPU fp32, greedy, KV append off. The reference keeps the extrapolation state on the
+    pipeline object, so every run uses a fresh pipeline."""
+    import shutil
+    import tempfile
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "llm-inference-lab_amd")
+    sys.path.append(pkg)                    # for this repo's weight builders (specdec_hip) only: appended, so that ...
+    pairs = cases.g8_pairs(torch.float32)
+    for m in [m for m in sys.modules if m == "specdec" or m.startswith("specdec.")]:
+        del sys.modules[m]
+    sys.path.insert(0, os.path.join(REF, "src"))   # ... the reference wins the name `specdec`
+    from specdec import SpeculativePipeline  # the reference
+
+    assert REF in os.path.abspath(sys.modules["specdec"].__file__), sys.modules["specdec"].__file__
+    tcfg = pairs["structured"][1].config
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="g8e_")
+    try:
+        for pname, (d, t) in pairs.items():
+            ddir, tdir = os.path.join(tmp, pname + "_draft"), os.path.join(tmp, pname + "_target")
+            _save_local_hf_llama(d, ddir)
+            _save_local_hf_llama(t, tdir)
+            out[pname] = {"target_checksum": cases.weights_checksum(t), "runs": []}
+            rng = np.random.default_rng(17)
+            for k in (1, 2, 4):
+                for max_tokens, plen in ((10, 6), (16, 9)):
+                    prompt_ids = rng.integers(4, tcfg.vocab, size=plen).tolist()
+                    prompt = " ".join(f"t{i:03d}" for i in prompt_ids)
+                    pipe = SpeculativePipeline(base_model=tdir, draft_model=ddir, implementation="hf", device="cpu",
+                                               controller="fixed", controller_params={"k": k}, max_draft=k, seed=1234,
+                                               draft_mode="eagle")
+                    rs = pipe.generate(prompt, max_tokens=max_tokens, temperature=0.7, do_sample=False)
+                    ecfg = pipe.config.get("eagle", {})
+                    out[pname]["runs"].append({
+                        "k": k, "alpha": float(ecfg.get("alpha", 0.7)), "max_draft": int(ecfg.get("max_draft", 2)),
+                        "max_tokens": max_tokens, "prompt_ids": prompt_ids,
+                        "single": {"generated_tokens": [int(x) for x in rs["generated_tokens"]] if "generated_tokens" in rs else None,
+                                   "text": rs.get("text"), "proposed": int(rs["proposed"]), "accepted": int(rs["accepted"]),
+                                   "steps": int(rs["steps"])},
+                    })
+                    print(pname, "eagle k", k, rs.get("text", "")[:70], rs["accepted"], "/", rs["proposed"], "steps", rs["steps"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(HERE, "pipeline_eagle_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+
+
 def gen_hostlogic():
     """G3-G6: the reference's host-side pieces on seeded inputs (policies, bonus-token
     filtering, controllers, sequence utils, token validation)."""
@@ -298,5 +349,7 @@ if __name__ == "__main__":
         gen_hf()
     if "pipeline" in which:
         gen_pipeline()
+    if "pipeline_eagle" in which:
+        gen_pipeline_eagle()
     if "hostlogic" in which:
         gen_hostlogic()

@@ -264,10 +264,35 @@ def test_medusa_lite_tied_heads_generate(k):
     assert got["generated_tokens"] == greedy[0].tolist()
     with pytest.raises(ValueError, match="draft model"):
         pipe.generate_batch([prompt], max_tokens=4, do_sample=False)
-    from src.specdec import SpeculativePipeline as SP
 
-    with pytest.raises(NotImplementedError, match="eagle"):
-        SP(base_lm=HipLM(tgt.to("cuda")), draft_lm=HipLM(drf.to("cuda")), draft_mode="eagle")
+
+@pytest.mark.parametrize("k,max_draft", [(4, 2), (4, 4), (1, 2), (8, 8)])
+def test_eagle_lite_generate(k, max_draft):
+    """draft_mode='eagle' (generate() only, as in the reference): min(k, eagle.max_draft) draft tokens per step from the
+    lm_head over hidden states extrapolated on the device (sd_specdec_set_eagle; the reference's _run_eagle_hf,
+    pipeline.py:765-889). Tokens, counters and steps equal the oracle's restatement — which reproduces the reference's
+    own eagle runs (tests/test_oracle_pipeline.py) — the text equals plain greedy decoding of the target, and a second
+    run on the same pipeline starts from a clean extrapolation state."""
+    from src.specdec import HipLM, SpeculativePipeline
+
+    drf, tgt = tiny_pair()
+    prompt = synthetic_prompts(1, 10, tgt.config.vocab)[0].tolist()
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt.to("cuda")), draft_model="none", draft_mode="eagle", controller="fixed",
+                               controller_params={"k": k}, seed=1234)
+    pipe.config["eagle"] = {"enabled": True, "alpha": 0.7, "max_draft": max_draft}
+    got = pipe.generate(prompt, max_tokens=14, do_sample=False)
+    lm = OracleLM(tgt, "bf16")
+    ke = min(k, max_draft)
+    want = OraclePipeline(lm, None, k=ke, eos_token_id=tgt.config.eos_token_id, draft_mode="eagle", eagle_alpha=0.7).generate(prompt, 14)
+    assert got["generated_tokens"] == want["generated_tokens"]
+    assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
+    assert got["proposed"] == ke * got["steps"] and got["draft_mode"] == "eagle"
+    greedy, _ = lm.generate_tokens(torch.tensor([prompt]), 14)
+    assert got["generated_tokens"] == greedy[0].tolist()
+    again = pipe.generate(prompt, max_tokens=14, do_sample=False)
+    assert (again["generated_tokens"], again["proposed"], again["accepted"]) == (got["generated_tokens"], got["proposed"], got["accepted"])
+    with pytest.raises(ValueError, match="draft model"):
+        pipe.generate_batch([prompt], max_tokens=4, do_sample=False)
 
 
 def test_generate_many_continuous_batching():
