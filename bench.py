@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: both models stream an OCP e4m3 copy of their Linear weights (per-row scales, bf16 activations and "
                          "MFMA); not the headline configuration (BASELINE config 2 is bf16), CPU parity leg uses the dequantised weights")
-    ap.add_argument("--draft-mode", choices=["vanilla", "medusa", "medusa-heads"], default="vanilla",
+    ap.add_argument("--draft-mode", choices=["vanilla", "medusa", "medusa-heads", "eagle"], default="vanilla",
                     help="medusa: BASELINE config 5's draft — Medusa-lite heads tied to the lm_head (the reference draftor's "
                          "semantics: K copies of the target's next token), single-prompt generate() loop, no draft model; "
                          "medusa-heads: K persistent heads over the target's last hidden state (not in the reference; synthetic heads, "
@@ -165,7 +165,7 @@ def main():
     log(f"rank {rank}/{world}: building {args.target} + {args.draft} weights on {device}")
     drf, tgt, source = build_models(args, device)
     wd = args.weight_dtype
-    medusa = args.draft_mode == "medusa"
+    medusa = args.draft_mode in ("medusa", "eagle")   # self-drafting generate() loops of the reference (no draft model, no bonus token)
     heads = None
     if args.draft_mode == "medusa-heads":
         from specdec_hip import weights as W
@@ -185,6 +185,7 @@ def main():
     sess = pipe.start_session(prompts, max_tokens=total_steps * (K + 1) + 1,
                               emit_mode=HipSpecDec.EMIT_DRAFT if medusa else HipSpecDec.EMIT_BONUS,
                               sampling=sampling, self_draft=medusa or heads is not None)
+    K = sess.k   # eagle: min(k, eagle.max_draft) proposals per step (reference default max_draft = 2)
 
     def barrier():
         if dist is not None:
@@ -237,7 +238,7 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
-        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{', Medusa-lite tied heads (self-draft), generate() loop' if medusa else ''}{', persistent Medusa heads (synthetic)' if heads is not None else ''}, "
+        "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{(', EAGLE-lite hidden-state extrapolation (self-draft), generate() loop' if args.draft_mode == 'eagle' else ', Medusa-lite tied heads (self-draft), generate() loop') if medusa else ''}{', persistent Medusa heads (synthetic)' if heads is not None else ''}, "
                                f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},
