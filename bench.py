@@ -153,6 +153,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # one process per GPU on one host: keep each rank's host-side torch pool to its share of the cores (the step
+        # loop itself is one Python thread launching a graph and reading a 68-byte record per step)
+        try:
+            share = max(1, len(os.sched_getaffinity(0)) // world)
+        except AttributeError:
+            share = max(1, (os.cpu_count() or world) // world)
+        torch.set_num_threads(share)
+
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
