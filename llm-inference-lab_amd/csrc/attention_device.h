@@ -200,17 +200,25 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
         mine[kAttnRows * D + kAttnRows + r] = den;
       }
     }
-    __threadfence();       // release the partial at device scope ...
+    // Release / acquire by ONE thread per workgroup: an agent-scope fence is a cache-wide L2 write-back / invalidate —
+    // one per wave of every workgroup adds up. Every thread waits for its own partial stores, the workgroup barrier
+    // orders them before thread 0's release fence (cumulative), the arrival is counted after it; the last arrival's
+    // acquire fence is ordered before everyone's reads by the second barrier.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(m_s);  // LDS scratch (m_s is dead after the loop above)
     if (tid == 0) {
-      const unsigned old = atomicAdd(a.split_cnt + group, 1u);   // ... before the arrival is counted
-      *flag = (old == static_cast<unsigned>(s_eff - 1)) ? 1u : 0u;
-      if (old == static_cast<unsigned>(s_eff - 1)) a.split_cnt[group] = 0u;  // ready for the next launch
+      __threadfence();       // release the partial at device scope before the arrival is counted
+      const unsigned old = atomicAdd(a.split_cnt + group, 1u);
+      const bool last = (old == static_cast<unsigned>(s_eff - 1));
+      *flag = last ? 1u : 0u;
+      if (last) {
+        a.split_cnt[group] = 0u;  // ready for the next launch
+        __threadfence();     // acquire: the other workgroups' partials
+      }
     }
     __syncthreads();
     if (*flag == 0u) return;
-    __threadfence();       // acquire: the other workgroups' partials
     const float* base = a.split_ws + static_cast<size_t>(group) * a.n_split * PS;
     // (max, sum) of every partial into LDS, then each thread owns 8 consecutive channels of one row and
     // streams its slice of the s_eff partial tiles with independent 16-byte loads
