@@ -145,6 +145,24 @@ def step_rules_single(row: RowState, k: int, a: int, draft: Sequence[int], t: Se
     return new
 
 
+def medusa_draftor_ref(base: OracleLM, ids: torch.Tensor, k: int, num_heads: int, temperature: float) -> List[int]:
+    """MedusaDraftor.generate_tokens (src/specdec/modes/medusa.py:104-186) with head_init "tie" / "copy" and top_p = 1:
+    every head is the base lm_head, evaluated on the same last hidden state (hidden_states[-1], i.e. after the final
+    norm) for each of the k proposals; each head in range draws once per proposal from softmax(logits / T) with
+    torch.multinomial (global generator); head 0's draw is the proposal. T -> 0 is the greedy limit."""
+    base.forward(ids)
+    h = base._norm(base.last_hidden[:, -1:, :], "nf", base.w.final_norm_w, base.w.final_norm_b)
+    lg = base._r(torch.nn.functional.linear(h, base._m("lm_head", base.w.lm_head)))
+    if temperature > 0:
+        lg = lg / temperature
+    probs = torch.softmax(lg, dim=-1).squeeze(1)
+    out = []
+    for step in range(k):
+        toks = [torch.multinomial(probs, 1) for _ in range(min(num_heads, k - step))]
+        out.append(int(toks[0][0, 0]))
+    return out
+
+
 class OraclePipeline:
     """The reference loop on CPU. `reprefill=True` re-feeds the whole prefix for every
     one of the 2K forwards of a step, as the reference does with KV append off
@@ -153,7 +171,8 @@ class OraclePipeline:
     same tokens faster (used by the parity tests)."""
 
     def __init__(self, base: OracleLM, draft: Optional[OracleLM], k: int = 4, eos_token_id: Optional[int] = None,
-                 reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None, eagle_alpha: float = 0.7):
+                 reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None, eagle_alpha: float = 0.7,
+                 medusa_num_heads: int = 2, medusa_temperature: float = 0.7):
         """draft_mode "medusa_tied": the reference's MedusaDraftor (src/specdec/modes/medusa.py:71-186) with
         head_init tie/copy under greedy decoding — every head is the base lm_head and head 0 is evaluated on the
         same last hidden state for each of the K proposals, so the draft is K copies of the base model's own
@@ -168,6 +187,8 @@ class OraclePipeline:
         # is the caller's. State per row = the LAST extrapolated hidden row of the previous step (what
         # `_eagle_last_hidden_states[:, -1:]` holds when the next call concatenates the new hidden state to it).
         self.eagle_alpha = float(eagle_alpha)
+        # "medusa_random": the reference PIPELINE's Medusa mode (_run_medusa_hf): fresh random heads per call, sampled
+        self.medusa_num_heads, self.medusa_temperature = int(medusa_num_heads), float(medusa_temperature)
         self._eagle_state: Dict[int, torch.Tensor] = {}
         self._next_draft: Dict[int, List[int]] = {}
         self.eos = eos_token_id
@@ -191,6 +212,8 @@ class OraclePipeline:
             return draft, t, a
         if self.draft_mode == "eagle":
             draft = self._eagle_draft(ids, row, k)
+        elif self.draft_mode == "medusa_random":
+            draft = self._medusa_random_draft(ids, k)
         elif self.draft_mode == "medusa_tied":
             t0, _ = self.base.generate_tokens(ids, 1, reprefill=self.reprefill)
             draft = [int(t0[0, 0])] * k
@@ -219,6 +242,34 @@ class OraclePipeline:
         t = self.last_logits.argmax(-1).tolist()
         a = longest_prefix(draft, t)
         return draft, t, a
+
+    def _medusa_random_draft(self, ids: torch.Tensor, k: int) -> List[int]:
+        """pipeline.py:655-763 (_run_medusa_hf), what draft_mode="medusa" runs for HF models: on EVERY call `num_heads`
+        fresh `nn.Linear(hidden, vocab, bias=False)` heads are created (their default init draws from the global
+        generator) and re-initialised with normal_(0, 0.02); all heads read the SAME last hidden state (after the final
+        norm: hidden_states[-1]) for every one of the k proposals; every head still in range draws one token with
+        torch.multinomial from softmax(logits / T) (global generator), and the proposal of a step is head 0's draw.
+        The restatement consumes the global torch generator in the same order, so under torch.manual_seed it replays
+        the reference's draws. (bf16 mode: heads and logits rounded to bf16, as a bf16 engine holds them.)"""
+        b = self.base
+        b.forward(ids)
+        h = b._norm(b.last_hidden[:, -1:, :], "nf", b.w.final_norm_w, b.w.final_norm_b)     # [1][1][d]
+        heads = []
+        for _ in range(self.medusa_num_heads):
+            head = torch.nn.Linear(b.cfg.d_model, self.vocab, bias=False)
+            torch.nn.init.normal_(head.weight, 0, 0.02)
+            heads.append(b._r(head.weight.detach()))
+        self.last_medusa_heads = heads
+        draft = []
+        for step in range(k):
+            toks = []
+            for hi in range(min(self.medusa_num_heads, k - step)):
+                lg = b._r(torch.nn.functional.linear(h, heads[hi]))                        # [1][1][V]
+                if self.medusa_temperature > 0:
+                    lg = lg / self.medusa_temperature
+                toks.append(torch.multinomial(torch.softmax(lg, dim=-1).squeeze(1), 1))
+            draft.append(int(toks[0][0, 0]))
+        return draft
 
     def _eagle_draft(self, ids: torch.Tensor, row: int, k: int) -> List[int]:
         """pipeline.py:786-858: h_t = last hidden state (after the final norm) of the last position; states = [E, h_t]

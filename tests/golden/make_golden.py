@@ -18,6 +18,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("SPECDEC_REFERENCE", "/root/reference")
+OUT = os.environ.get("SPECDEC_GOLDEN_OUT", HERE)   # where the fixtures are written (a test regenerates them elsewhere)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(REF, "src"))
 sys.path.insert(0, REF)
@@ -63,9 +64,9 @@ def gen_kernels():
             arrays[f"{name}/concat_v"] = ov.float().numpy()
             arrays[f"{name}/masked_k"] = mk.float().numpy()
             arrays[f"{name}/masked_v"] = mv.float().numpy()
-    with open(os.path.join(HERE, "kernels_golden.json"), "w") as f:
+    with open(os.path.join(OUT, "kernels_golden.json"), "w") as f:
         json.dump(out, f, indent=1)
-    np.savez_compressed(os.path.join(HERE, "kernels_golden.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, "kernels_golden.npz"), **arrays)
     print("kernels goldens:", len(out["verify"]), "verify cases,", len(out["kv"]), "kv cases")
 
 
@@ -107,11 +108,11 @@ def gen_hf():
         arrays = {"__tokens": toks.numpy(), "__logits": logits.numpy()}
         for k, v in model.state_dict().items():
             arrays[k] = v.detach().float().numpy()
-        np.savez_compressed(os.path.join(HERE, f"hf_{name}_tiny.npz"), **arrays)
+        np.savez_compressed(os.path.join(OUT, f"hf_{name}_tiny.npz"), **arrays)
         meta = {"transformers": transformers.__version__, "torch": torch.__version__,
                 "config": {k: v for k, v in cfg.to_dict().items()
                            if isinstance(v, (int, float, str, bool, dict, type(None)))}}
-        with open(os.path.join(HERE, f"hf_{name}_tiny.json"), "w") as f:
+        with open(os.path.join(OUT, f"hf_{name}_tiny.json"), "w") as f:
             json.dump(meta, f, indent=1, default=str)
         print("hf golden:", name, tuple(logits.shape))
 
@@ -155,19 +156,38 @@ def _save_local_hf_llama(mw, path):
     fast.save_pretrained(path)
 
 
+def _reference_pipeline_class():
+    """`SpeculativePipeline` of the REFERENCE, never this repo's: the product ships packages of the same names
+    (`specdec`, `kernels`, `src`) under llm-inference-lab_amd/, so that directory goes to the END of sys.path (it is only
+    needed for the weight builders in `specdec_hip`, a name the reference does not have), every already-imported
+    `specdec*` / `kernels*` / `src*` module is dropped, REF/src and REF lead the path, and the origin of what was
+    imported is asserted before anything is generated from it."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "llm-inference-lab_amd")
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != pkg]
+    sys.path.append(pkg)
+    for m in [m for m in sys.modules if m.split(".")[0] in ("specdec", "kernels", "src", "scheduler")]:
+        del sys.modules[m]
+    for p in (REF, os.path.join(REF, "src")):
+        if p in sys.path:
+            sys.path.remove(p)
+        sys.path.insert(0, p)
+    from specdec import SpeculativePipeline
+
+    for name in ("specdec", "kernels"):
+        origin = os.path.abspath(sys.modules[name].__file__)
+        assert origin.startswith(os.path.abspath(REF) + os.sep), f"{name} was imported from {origin}, not from the reference"
+    return SpeculativePipeline
+
+
 def gen_pipeline():
     """G8: traces of the REFERENCE SpeculativePipeline on local tiny Llama pairs (CPU, fp32,
     greedy, KV append off — the configuration of its published runs)."""
     import shutil
     import tempfile
 
-    pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "llm-inference-lab_amd")
-    sys.path.insert(0, pkg)
-    from specdec_hip import weights as W  # weight builders only (data), not the HIP path
-
     os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
     os.environ["SPECDEC_DETERMINISTIC"] = "1"
-    from specdec import SpeculativePipeline  # the reference (REF/src on sys.path)
+    SpeculativePipeline = _reference_pipeline_class()
 
     pairs = cases.g8_pairs(torch.float32)
     tcfg = pairs["structured"][1].config
@@ -204,7 +224,7 @@ def gen_pipeline():
                           "| single", rs.get("text", "")[:60], rs["accepted"], "/", rs["proposed"])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    with open(os.path.join(HERE, "pipeline_golden.json"), "w") as f:
+    with open(os.path.join(OUT, "pipeline_golden.json"), "w") as f:
         json.dump(out, f, indent=1, default=str)
 
 
@@ -217,15 +237,8 @@ def gen_pipeline_eagle():
 
     os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
     os.environ["SPECDEC_DETERMINISTIC"] = "1"
-    pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "llm-inference-lab_amd")
-    sys.path.append(pkg)                    # for this repo's weight builders (specdec_hip) only: appended, so that ...
+    SpeculativePipeline = _reference_pipeline_class()
     pairs = cases.g8_pairs(torch.float32)
-    for m in [m for m in sys.modules if m == "specdec" or m.startswith("specdec.")]:
-        del sys.modules[m]
-    sys.path.insert(0, os.path.join(REF, "src"))   # ... the reference wins the name `specdec`
-    from specdec import SpeculativePipeline  # the reference
-
-    assert REF in os.path.abspath(sys.modules["specdec"].__file__), sys.modules["specdec"].__file__
     tcfg = pairs["structured"][1].config
     out = {}
     tmp = tempfile.mkdtemp(prefix="g8e_")
@@ -255,7 +268,79 @@ def gen_pipeline_eagle():
                     print(pname, "eagle k", k, rs.get("text", "")[:70], rs["accepted"], "/", rs["proposed"], "steps", rs["steps"])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    with open(os.path.join(HERE, "pipeline_eagle_golden.json"), "w") as f:
+    with open(os.path.join(OUT, "pipeline_eagle_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+
+
+def gen_medusa():
+    """Medusa-lite as the reference has it, on the G8 target models (CPU fp32, KV append off):
+      draftor  — `MedusaDraftor` (src/specdec/modes/medusa.py:17-186, head_init="tie"): its proposals for a prompt at
+                 temperature 1e-6 (softmax(logits / T) is one-hot: the greedy limit, which pins the oracle's
+                 draft_mode="medusa_tied") and at temperature 0.7 under torch.manual_seed (pins the draw order);
+      pipeline — `SpeculativePipeline(draft_mode="medusa").generate()` = _run_medusa_hf (pipeline.py:655-763): fresh
+                 nn.Linear heads with normal_(0, 0.02) weights and multinomial draws from the GLOBAL torch generator on
+                 every step; torch.manual_seed(run seed) is called right before generate() so that a restatement can
+                 replay the generator."""
+    import shutil
+    import tempfile
+
+    import transformers
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    SpeculativePipeline = _reference_pipeline_class()
+    from specdec.modes.medusa import MedusaDraftor
+
+    assert os.path.abspath(sys.modules["specdec.modes.medusa"].__file__).startswith(os.path.abspath(REF) + os.sep)
+    pairs = cases.g8_pairs(torch.float32)
+    tcfg = pairs["structured"][1].config
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="g8m_")
+    try:
+        for pname, (d, t) in pairs.items():
+            ddir, tdir = os.path.join(tmp, pname + "_draft"), os.path.join(tmp, pname + "_target")
+            _save_local_hf_llama(d, ddir)
+            _save_local_hf_llama(t, tdir)
+            out[pname] = {"target_checksum": cases.weights_checksum(t), "draftor": [], "pipeline": []}
+            model = transformers.AutoModelForCausalLM.from_pretrained(tdir).eval()
+            tok = transformers.AutoTokenizer.from_pretrained(tdir)
+            rng = np.random.default_rng(23)
+            for k in (1, 2, 4):
+                for plen in (5, 11):
+                    prompt_ids = rng.integers(4, tcfg.vocab, size=plen).tolist()
+                    ids = torch.tensor([prompt_ids], dtype=torch.int64)
+                    greedy = MedusaDraftor(model, tok, num_heads=k, head_init="tie", temperature=1e-6, device="cpu")
+                    g_ids, _, _ = greedy.generate_tokens(ids, k)
+                    seed = 31000 + 10 * k + plen
+                    sampled = MedusaDraftor(model, tok, num_heads=k, head_init="tie", temperature=0.7, device="cpu")
+                    torch.manual_seed(seed)
+                    s_ids, s_logits, _ = sampled.generate_tokens(ids, k)
+                    out[pname]["draftor"].append({
+                        "k": k, "prompt_ids": prompt_ids, "vocab_size": int(tok.vocab_size), "greedy_limit": g_ids[0].tolist(),
+                        "seed": seed, "temperature": 0.7, "sampled": s_ids[0].tolist(),
+                        "head0_logits_checksum": cases.checksum(s_logits)})
+            rng = np.random.default_rng(29)
+            for k in (1, 2, 4):
+                for max_tokens, plen in ((10, 6), (14, 9)):
+                    prompt_ids = rng.integers(4, tcfg.vocab, size=plen).tolist()
+                    prompt = " ".join(f"t{i:03d}" for i in prompt_ids)
+                    pipe = SpeculativePipeline(base_model=tdir, draft_model=ddir, implementation="hf", device="cpu",
+                                               controller="fixed", controller_params={"k": k}, max_draft=k, seed=1234,
+                                               draft_mode="medusa")
+                    seed = 32000 + 100 * k + max_tokens
+                    torch.manual_seed(seed)
+                    rs = pipe.generate(prompt, max_tokens=max_tokens, temperature=0.7, do_sample=False)
+                    mcfg = pipe.config.get("medusa", {})
+                    out[pname]["pipeline"].append({
+                        "k": k, "num_heads": int(mcfg.get("num_heads", 2)), "temperature": 0.7, "seed": seed,
+                        "max_tokens": max_tokens, "prompt_ids": prompt_ids,
+                        "single": {"generated_tokens": [int(x) for x in rs["generated_tokens"]] if "generated_tokens" in rs else None,
+                                   "text": rs.get("text"), "proposed": int(rs["proposed"]), "accepted": int(rs["accepted"]),
+                                   "steps": int(rs["steps"])}})
+                    print(pname, "medusa k", k, rs.get("text", "")[:70], rs["accepted"], "/", rs["proposed"], "steps", rs["steps"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "medusa_golden.json"), "w") as f:
         json.dump(out, f, indent=1, default=str)
 
 
@@ -335,7 +420,7 @@ def gen_hostlogic():
             counts[t] = counts.get(t, 0) + 1
         out["sampling"].append({"seed": seed, "V": V, "scale": scale, "bf16": case % 5 == 4, "top_k": top_k, "top_p": top_p,
                                 "temperature": temp, "n_draws": n_draws, "counts": {str(k): v for k, v in sorted(counts.items())}})
-    with open(os.path.join(HERE, "hostlogic_golden.json"), "w") as f:
+    with open(os.path.join(OUT, "hostlogic_golden.json"), "w") as f:
         json.dump(out, f)
     print("hostlogic goldens:", {k: len(v) for k, v in out.items()})
 
@@ -353,3 +438,5 @@ if __name__ == "__main__":
         gen_pipeline_eagle()
     if "hostlogic" in which:
         gen_hostlogic()
+    if "medusa" in which:
+        gen_medusa()
