@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 40 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: bench.py starts the N ranks itself, see launch_ranks)
 
 Workload (BASELINE.json configs[1]): Llama-3.2-3B target + Llama-3.2-1B draft shapes, K = 4,
 batch 1 per GPU, bf16, synthetic prompts (32 ids, generator seed 1234+i) and architecture-
@@ -67,6 +68,9 @@ def parse():
                          "semantics: K copies of the target's next token), single-prompt generate() loop, no draft model; "
                          "medusa-heads: K persistent heads over the target's last hidden state (not in the reference; synthetic heads, "
                          "--flip of their rows wrong), generate_batch loop")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only (CPU tests of --gpus N): every rank initialises its process group, contributes a "
+                         "fixed stats struct to the all-gather and rank 0 prints n_gpus; nothing is decoded or timed")
     ap.add_argument("--do-sample", action="store_true",
                     help="sampled bonus token (T=0.7, top_k=50, top_p=0.9: the reference's default sampler) instead of greedy; "
                          "not the headline configuration (SPECDEC_DETERMINISTIC is greedy), no CPU parity leg")
@@ -134,11 +138,91 @@ def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows, weight_dtype="bf16"):
     }, bool(same)
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run as a CHILD
+    process (one rank per GPU, rendezvous on 127.0.0.1, a free port) and return its exit code; rank 0's JSON line goes
+    to this process's stdout unchanged. Called before anything in this process has touched the GPU — the ranks are
+    fresh processes, nothing is re-exec'ed."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:])}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def bind_to_gpu_numa(local: int, ranks_on_host: int) -> dict:
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (the step loop is one Python
+    thread launching a graph and reading a pinned record per step, so it should sit next to its GPU's PCIe root):
+    /sys/bus/pci/devices/<bdf of cuda:local>/{numa_node,local_cpulist}, intersected with the affinity mask the job was
+    given. Leaves the mask alone when sysfs has no answer (numa_node -1, container without the files)."""
+    info = {"numa_node": None, "cpus": None}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        with open(f"{base}/numa_node") as f:
+            node = int(f.read().strip())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        with open(f"{base}/local_cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info["cpus"] = len(cpus)
+    except (AttributeError, OSError, ValueError):
+        pass
+    return info
+
+
+def dry_run(args, world, rank):
+    """Launch plumbing without a GPU (tests/test_bench_launch.py): process group over gloo, the one all-gather, rank 0
+    prints how many ranks contributed. Nothing is decoded, timed or reported as a measurement."""
+    from specdec_hip.dist_stats import gather_stats
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        dist.barrier()
+    job = gather_stats({"tokens": rank + 1, "proposed": 4, "accepted": 1, "accepted_strict": 0, "wall_ns": 10 ** 9, "steps": 1},
+                       torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": int(job.per_rank.shape[0]), "tokens": job.total("tokens"), "value": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback to time)")
     # SPECDEC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: every rank
@@ -166,6 +250,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    numa = bind_to_gpu_numa(local, world) if not rehearsal else {"numa_node": None, "cpus": None}
 
     from src.specdec import HipLM, SpeculativePipeline
     from specdec_hip.engine import HipSpecDec
@@ -253,7 +338,8 @@ def main():
         bytes_step //= 2      # one byte per weight (+ 4 bytes per output row of scales: < 0.1 %)
     out = {
         "metric": "accepted tokens/sec + acceptance-rate, Llama-3.2-3B/1B K=4 @1/2/4/8 GPU",
-        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "tokens/s", "n_gpus": int(job.per_rank.shape[0]),   # ranks that contributed to the all-gather
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
         "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{(', EAGLE-lite hidden-state extrapolation (self-draft), generate() loop' if args.draft_mode == 'eagle' else ', Medusa-lite tied heads (self-draft), generate() loop') if medusa else ''}{', persistent Medusa heads (synthetic)' if heads is not None else ''}, "
@@ -266,21 +352,11 @@ def main():
         "step_bytes": bytes_step,
         "step_roofline_frac": bytes_step / (ms_per_step / 1e3) / HBM_PEAK_BPS,
         "resyncs": sess.stats["resyncs"],
+        "rank0_numa": numa, "collective_backend": ("gloo (rehearsal: all ranks on cuda:0)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
         # one-off H2D of the prompt ids of this rank's rows, measured, and the rate with it added to the timed region
         "h2d_prompt_us": h2d_s * 1e6,
         "value_pcie_inclusive": tokens / (t_max + h2d_s),
     }
-    # chained GEMV launches (csrc/gemv_chain.hip): opt-in (SPECDEC_CHAIN_PAIRS), off in the headline run; a barrier
-    # that ever timed out invalidates the run
-    chained = {}
-    for name in ("target", "draft"):
-        hm = sess.rt.get(name) if hasattr(sess.rt, "get") else None
-        if hm is not None and hasattr(hm, "chain_status"):
-            en, timed_out = hm.chain_status()
-            if timed_out:
-                raise RuntimeError(f"{name}: an in-kernel grid barrier of the chained GEMV launches timed out")
-            chained[name] = en
-    out["chained_launches"] = chained
     log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} tok/s")
     # ---- roofline of the dominant kernel, timed live with HIP events --------------------
     if not args.no_probe:

@@ -264,15 +264,6 @@ int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride,
 int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, void* stream,
                         float* avg_usec, double* bytes_per_launch);
 
-/* Chained launches (csrc/gemv_chain.hip; experimental, OFF unless SPECDEC_CHAIN_PAIRS is set when the model is
- * bound: bit 0 = [out-projection -> gate/up], bit 1 = [down projection -> next layer's QKV]): at <= 9 tokens per pass a
- * Llama forward runs the pair as ONE kernel, the two matrices separated by an in-kernel fence-free grid barrier
- * (same arithmetic, same bits; measured SLOWER than two launches on MI355X).
- * *enabled = 1 when the bound model uses them; *timed_out = 1 when a barrier wait ever hit its poll limit (results
- * of that forward are invalid: the caller must treat it as an error). Synchronises the device. No counterpart in
- * the reference (its forward is HF eager mode, hf_wrappers.py:417/478). */
-int sd_model_chain_status(sd_model* m, int* enabled, int* timed_out);
-
 /* ---- the step loop ------------------------------------------------------- */
 typedef struct sd_specdec sd_specdec;
 

@@ -38,12 +38,6 @@ struct sd_model {
   int32_t* probe_pos = nullptr;  // [1] zero: position base of the QKV probe
   float* attn_ws = nullptr;      // split-KV partial tiles (attention.hip)
   unsigned* attn_cnt = nullptr;  // arrival counters, zero between launches
-  unsigned* chain_sync = nullptr; // grid-barrier counters of the chained GEMV launches (gemv_chain.hip), monotonic
-  unsigned* chain_err = nullptr;  // set by a workgroup whose barrier wait timed out
-  // Chained launches are OFF by default: measured slower than separate launches ("in-kernel barrier").
-  // SPECDEC_CHAIN_PAIRS = bit 0: [out-projection -> gate/up], bit 1: [down projection -> next QKV].
-  bool chain = false;
-  int chain_pairs = 0;
   float* part_val = nullptr; // [64][512]
   int small_t = sd::kGemvMaxT; // tokens per pass of gemv.hip for this model's widest activation row (<= 9)
   int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
@@ -71,7 +65,6 @@ static size_t workspace_bytes(const sd_model_config& c) {
   n += align_up(T * c.d_ff * 2, 256);
   n += align_up(T * kMaxPartials * 4, 256) * 2;
   n += align_up(attention_split_ws_bytes(c.head_dim), 256);
-  n += align_up(chain_sync_bytes(), 256);
   return n + 256;
 }
 
@@ -102,12 +95,6 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   if (int rc = launch_embed(e, st)) return rc;
 
   const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
-  // Chained launches (gemv_chain.hip, opt-in with SPECDEC_CHAIN_PAIRS): [out-projection -> gate/up] and
-  // [down projection -> QKV of the next layer] as ONE kernel each, separated by an in-kernel grid barrier:
-  // 3 launches per layer instead of 5. `pend` is the down projection waiting for its partner.
-  const bool chain = m->chain && T <= kGemvMaxT;
-  GemvArgs pend{};
-  bool have_pend = false;
   for (int l = 0; l < c.n_layers; ++l) {
     const sd_layer_weights& w = m->layers[l];
     uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
@@ -147,14 +134,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     a1.rope_sin = llama ? c.rope_sin : nullptr;
     a1.k_cache = kc;
     a1.v_cache = vc;
-    if (have_pend && chain && (m->chain_pairs & 2) && gemv_chain_covers(pend, a1, EPI_QKV_ROPE)) {
-      if (int rc = launch_gemv_chain(pend, a1, EPI_QKV_ROPE, m->chain_sync, m->chain_err, st)) return rc;
-    } else {
-      if (have_pend)
-        if (int rc = launch_gemv(pend, EPI_RESID, st)) return rc;
-      if (int rc = launch_gemv(a1, EPI_QKV_ROPE, st)) return rc;
-    }
-    have_pend = false;
+    if (int rc = launch_gemv(a1, EPI_QKV_ROPE, st)) return rc;
 
     // 2. attention of the Mc new positions over the appended cache
     AttnArgs at{};
@@ -207,12 +187,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     if (llama) {
       a4.N = 2 * ff;
       a4.n_pairs = ff;
-      if (chain && (m->chain_pairs & 1) && gemv_chain_covers(a3, a4, EPI_SWIGLU)) {
-        if (int rc = launch_gemv_chain(a3, a4, EPI_SWIGLU, m->chain_sync, m->chain_err, st)) return rc;
-      } else {
-        if (int rc = launch_gemv(a3, EPI_RESID, st)) return rc;
-        if (int rc = launch_gemv(a4, EPI_SWIGLU, st)) return rc;
-      }
+      if (int rc = launch_gemv(a3, EPI_RESID, st)) return rc;
+      if (int rc = launch_gemv(a4, EPI_SWIGLU, st)) return rc;
     } else {
       a4.N = ff;
       a4.n_pairs = ff / 2;
@@ -233,11 +209,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     a5.prologue = PRO_NONE;
     a5.out = m->x;
     a5.out_stride = d;
-    pend = a5;
-    have_pend = true;
+    if (int rc = launch_gemv(a5, EPI_RESID, st)) return rc;
   }
-  if (have_pend)
-    if (int rc = launch_gemv(pend, EPI_RESID, st)) return rc;
   if (skip_head) return 0;
 
   // final norm + lm_head with the argmax fused into the epilogue
@@ -438,11 +411,6 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->attn_ws = reinterpret_cast<float*>(p);
   m->attn_cnt = reinterpret_cast<unsigned*>(p + static_cast<size_t>(kAttnSplitSlots) * 16 * (c.head_dim + 2) * sizeof(float));
   p += align_up(attention_split_ws_bytes(c.head_dim), 256);
-  m->chain_sync = reinterpret_cast<unsigned*>(p);
-  m->chain_err = m->chain_sync + (chain_sync_bytes() - 256) / sizeof(unsigned);
-  SD_HIP_CHECK(hipMemset(m->chain_sync, 0, chain_sync_bytes()));
-  m->chain_pairs = getenv("SPECDEC_CHAIN_PAIRS") ? atoi(getenv("SPECDEC_CHAIN_PAIRS")) : 0;
-  m->chain = (c.arch == SD_ARCH_LLAMA) && (m->chain_pairs & 3) != 0;
   SD_HIP_CHECK(hipMemset(m->attn_cnt, 0, kAttnSplitSlots * sizeof(unsigned)));
   m->probe_pos = reinterpret_cast<int32_t*>(m->attn_cnt);   // a zero word (the counters rest at zero between launches)
   return 0;
@@ -454,20 +422,6 @@ extern "C" int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stri
   clear_error();
   return model_forward(m, tokens, tok_stride, pos_base, pos_off, row0, B, M, ids_out, ids_stride, logits_out,
                        logits_dtype, skip_head, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int sd_model_chain_status(sd_model* m, int* enabled, int* timed_out) {
-  clear_error();
-  SD_REQUIRE(m && enabled && timed_out, "chain_status: NULL argument");
-  *enabled = (m->chain && m->chain_sync) ? 1 : 0;
-  *timed_out = 0;
-  if (m->chain_err) {
-    unsigned e = 0;
-    SD_HIP_CHECK(hipDeviceSynchronize());
-    SD_HIP_CHECK(hipMemcpy(&e, m->chain_err, sizeof(e), hipMemcpyDeviceToHost));
-    *timed_out = e ? 1 : 0;
-  }
-  return 0;
 }
 
 // Measurement hook (bench.py "roofline" leg): one GEMV of the forward, launched `iters`
@@ -540,52 +494,9 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
         g.part_val = m->part_val; g.part_idx = m->part_idx;
         return launch_gemv(g, EPI_ARGMAX, st);
       default:
-        set_error("probe_gemv: which=%d (0=qkv 1=o_proj 2=gate_up 3=down 4=lm_head 5=o_proj+gate_up chained 6=down+qkv chained)", which);
+        set_error("probe_gemv: which=%d (0=qkv 1=o_proj 2=gate_up 3=down 4=lm_head)", which);
         return 1;
     }
-  };
-  // 5 / 6: the chained pairs of gemv_chain.hip (one launch = both matrices)
-  auto build = [&](int l, int w_, GemvArgs& g) {   // the arguments of launch(l) for kind w_, without launching
-    const sd_layer_weights& w = m->layers[l % c.n_layers];
-    const int li = l % c.n_layers;
-    g = GemvArgs{};
-    g.packed = m->is_packed(); g.w8 = m->w8(); g.T = T; g.M = T; g.out_dtype = SD_BF16; g.norm_eps = c.norm_eps;
-    g.w_scale = m->scale(4 * li + w_);
-    switch (w_) {
-      case 0: {
-        const int Hkv = c.n_kv_heads;
-        g.W = m->mat(4 * li + 0, w.wqkv); g.bias = w.bqkv; g.N = (Hq + 2 * Hkv) * D; g.K = d; g.n_pairs = g.N / 2;
-        g.x = m->x; g.x_stride = d; g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.attn_norm_w; g.norm_b = w.attn_norm_b;
-        g.out = m->q; g.out_stride = Hq * D; g.head_dim = D; g.n_q_heads = Hq; g.n_kv_heads = Hkv; g.max_pos = c.max_pos; g.l_max = m->Lmax;
-        g.rope_cos = llama ? c.rope_cos : nullptr; g.rope_sin = llama ? c.rope_sin : nullptr; g.pos_base = m->probe_pos; g.pos_off = 0;
-        const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
-        g.k_cache = m->k_cache + li * layer_kv; g.v_cache = m->v_cache + li * layer_kv;
-        break;
-      }
-      case 1:
-        g.W = m->mat(4 * li + 1, w.wo); g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
-        g.x = m->attn; g.x_stride = Hq * D; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
-        break;
-      case 2:
-        g.W = m->mat(4 * li + 2, w.w_up); g.bias = w.b_up; g.K = d; g.x = m->x; g.x_stride = d;
-        g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.mlp_norm_w; g.norm_b = w.mlp_norm_b;
-        g.out = m->act; g.out_stride = ff; g.N = 2 * ff; g.n_pairs = ff;
-        break;
-      default:
-        g.W = m->mat(4 * li + 3, w.w_down); g.bias = w.b_down; g.N = d; g.K = ff; g.n_pairs = d / 2;
-        g.x = m->act; g.x_stride = ff; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
-        break;
-    }
-  };
-  auto launch_pair = [&](int l) -> int {
-    GemvArgs a{}, b{};
-    build(l, which == 5 ? 1 : 3, a);
-    build(which == 5 ? l : l + 1, which == 5 ? 2 : 0, b);
-    a.debug_ts = dbg;
-    b.debug_ts = dbg;
-    const int epi_b = which == 5 ? EPI_SWIGLU : EPI_QKV_ROPE;
-    SD_REQUIRE(llama && gemv_chain_covers(a, b, epi_b), "probe_gemv: this model / token count has no chained launches");
-    return launch_gemv_chain(a, b, epi_b, m->chain_sync, m->chain_err, st);
   };
   double bytes = 0;
   switch (which) {
@@ -596,13 +507,11 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     default: bytes = 2.0 * c.vocab * d; break;
   }
   if (m->w8()) bytes *= 0.5;  // one byte per weight
-  const bool pair = (which == 5 || which == 6);
-  if (pair) bytes = 2.0 * d * (which == 5 ? Hq * D + 2 * ff : ff + (Hq + 2 * c.n_kv_heads) * D);
   for (int i = 0; i < 3; ++i)
-    if (int rc = pair ? launch_pair(hot > 0 ? i % hot : i) : launch(i)) return rc;
+    if (int rc = launch(i)) return rc;
   SD_HIP_CHECK(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i)
-    if (int rc = pair ? launch_pair(hot > 0 ? (i + 3) % hot : i + 3) : launch(i + 3)) return rc;
+    if (int rc = launch(i + 3)) return rc;
   SD_HIP_CHECK(hipEventRecord(e1, st));
   SD_HIP_CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -611,27 +520,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
   (void)hipEventDestroy(e1);
   *avg_usec = ms * 1000.0f / iters;
   *bytes_per_launch = bytes;
-  if (timeline && pair) {  // chained pair: 16 stamps per workgroup (phase 1: 0 entry, 3 staged, 4 mfma, 5 end, 6 stores acked; phase 2: 8 start, 9 prefetch issued, 10 barrier passed, 11 staged, 12 mfma, 13 end)
-    std::vector<unsigned long long> h(256 * 16);
-    SD_HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    (void)hipFree(dbg);
-    unsigned long long t0 = ~0ull;
-    for (int b = 0; b < 256; ++b)
-      if (h[b * 16]) t0 = h[b * 16] < t0 ? h[b * 16] : t0;
-    static const int slots[11] = {0, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13};
-    static const char* names[11] = {"p1 entry", "p1 staged", "p1 mfma", "p1 end", "acked", "p2 start", "p2 issued", "barrier", "p2 staged", "p2 mfma", "p2 end"};
-    fprintf(stderr, "[chain timeline which=%d T=%d] us from first entry (min / mean / max):\n", which, T);
-    for (int s = 0; s < 11; ++s) {
-      double mn = 1e30, mx = 0, sum = 0;
-      int n = 0;
-      for (int b = 0; b < 256; ++b) {
-        if (!h[b * 16 + slots[s]]) continue;
-        const double v = (h[b * 16 + slots[s]] - t0) / 100.0;
-        mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; ++n;
-      }
-      fprintf(stderr, "  %-10s %7.2f %7.2f %7.2f\n", names[s], mn, sum / (n ? n : 1), mx);
-    }
-  } else if (timeline) {  // stamps of the LAST launch: offsets from the earliest workgroup entry, in us
+  if (timeline) {  // stamps of the LAST launch: offsets from the earliest workgroup entry, in us
     std::vector<unsigned long long> h(256 * 8);
     SD_HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(dbg);

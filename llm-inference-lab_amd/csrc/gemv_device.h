@@ -66,8 +66,7 @@ __device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int
 // epilogues: one lane finishes token t of pair p (y0 = row r0, y1 = row r1)
 // ------------------------------------------------------------------------------
 //   COH (EPI_RESID only): the new residual row is stored with an agent-scope relaxed atomic store (write-through to
-//   memory) so that the second phase of a chained launch (gemv_chain.hip) can read it on another XCD after the
-//   in-kernel grid barrier without an L2 write-back.
+//   memory), for a consumer on another XCD inside the same launch.
 template <int EPI, bool COH = false>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
                                          float y1, float& best_v, int& best_i, bool have_old = false,

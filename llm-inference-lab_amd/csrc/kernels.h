@@ -93,10 +93,6 @@ int gemv_grid(const GemvArgs& a, int* ppw_out);
 int gemv_max_tokens(int K);                                          // tokens gemv.hip can stage for rows of K elements (<= 9)
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip
 int launch_gemm_skinny(const GemvArgs& a, int epi, hipStream_t st);   // T <= 64
-// gemv_chain.hip: [a: EPI_RESID] -> in-kernel grid barrier -> [b: norm + epi_b] as ONE launch (T <= 9, 256 workgroups)
-bool gemv_chain_covers(const GemvArgs& a, const GemvArgs& b, int epi_b);
-int launch_gemv_chain(const GemvArgs& a, const GemvArgs& b, int epi_b, unsigned* sync, unsigned* err, hipStream_t st);
-size_t chain_sync_bytes();                                            // barrier counters (+ error word), zeroed once
 bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8 = false);                  // shape handled by gemm_skinny.hip
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------

@@ -8,7 +8,8 @@ system info + detailed per-prompt rows. Two deliberate differences:
   * K is actually applied: the pipeline is built with controller_params={"k": K} (the reference
     passes only max_draft=K, which its controller ignores — every published "K-sweep" ran K=4,
     SURVEY §0.5);
-  * greedy decoding (do_sample=False): sampling is not on the HIP path yet.
+  * greedy decoding (do_sample=False, the SPECDEC_DETERMINISTIC configuration) unless --do-sample is given; the
+    reference script samples (T=0.7), which on the device is the sampled bonus token of the captured step.
 Prompts are tokenised by the model's tokenizer when a checkpoint directory provides one; with
 synthetic weights the suite is mapped to seeded token ids of the same lengths.
 

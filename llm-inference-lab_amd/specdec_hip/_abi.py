@@ -76,7 +76,6 @@ SIGNATURES = {
         [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
          _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     ),
-    "sd_model_chain_status": (_c_int, [_c_void_p, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "sd_model_probe_gemv": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]),
     "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),

@@ -148,15 +148,6 @@ class HipModel:
         """Tokens per forward pass (64 with the multi-token kernel, else 9)."""
         return int(self.lib.sd_model_pass_tokens(self.handle))
 
-    def chain_status(self):
-        """(enabled, timed_out) of the chained GEMV launches (sd_model_chain_status): timed_out means an in-kernel
-        grid barrier hit its poll limit and the forwards since then are invalid. Synchronises the device."""
-        en, to = ctypes.c_int(0), ctypes.c_int(0)
-        with torch.cuda.device(self.device):
-            rc = self.lib.sd_model_chain_status(self.handle, ctypes.byref(en), ctypes.byref(to))
-        _abi.check(rc, "sd_model_chain_status")
-        return bool(en.value), bool(to.value)
-
     PROBE_O, PROBE_GATE_UP, PROBE_DOWN, PROBE_LM_HEAD = 1, 2, 3, 4
 
     def probe_gemv(self, which: int, T: int, iters: int = 200, stream: Optional[torch.cuda.Stream] = None):

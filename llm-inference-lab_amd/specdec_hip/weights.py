@@ -400,6 +400,42 @@ def synthetic_gpt2(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.bf
     )
 
 
+def random_init(cfg: ModelConfig, seed: int = 0, std: float = 0.02, device="cpu", dtype=torch.bfloat16) -> ModelWeights:
+    """Plain random initialisation of the architecture `cfg` names, as `transformers` initialises an untrained
+    model (`initializer_range` 0.02: every Linear / embedding weight ~ N(0, std), norm weights 1) — except that
+    biases and the norm offsets are drawn ~ N(0, std) too instead of zero, so that every operand of the forward
+    carries information. No successor structure and no damped layers: argmax margins are whatever a random
+    network has, which is what a numerical (logit-level) comparison wants. `synthetic_llama` is the
+    token-parity counterpart."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    d, ff, V = cfg.d_model, cfg.d_ff, cfg.vocab
+    Hq, Hkv, D = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
+    llama = cfg.arch == ARCH_LLAMA
+
+    def w(*shape):
+        return _randn(shape, std, gen, device, dtype)
+
+    def ones_plus(n):
+        return (1.0 + _randn((n,), std, gen, device, torch.float32)).to(dtype)
+
+    tok = w(V, d)
+    head = tok if cfg.tie_embeddings else w(V, d)
+    layers = []
+    for _ in range(cfg.n_layers):
+        if llama:
+            layers.append(LayerWeights(attn_norm_w=ones_plus(d), wqkv=w((Hq + 2 * Hkv) * D, d), wo=w(d, Hq * D),
+                                       mlp_norm_w=ones_plus(d), w_up=w(2 * ff, d), w_down=w(d, ff)))
+        else:
+            layers.append(LayerWeights(attn_norm_w=ones_plus(d), attn_norm_b=w(d), wqkv=w(3 * d, d), bqkv=w(3 * d),
+                                       wo=w(d, d), bo=w(d), mlp_norm_w=ones_plus(d), mlp_norm_b=w(d),
+                                       w_up=w(ff, d), b_up=w(ff), w_down=w(d, ff), b_down=w(d)))
+    meta = {"synthetic": True, "seed": seed, "init": f"normal(0, {std})"}
+    if llama:
+        cos, sin = rope_tables(cfg, device)
+        return ModelWeights(cfg, tok, head, ones_plus(d), layers, rope_cos=cos, rope_sin=sin, meta=meta)
+    return ModelWeights(cfg, tok, head, ones_plus(d), layers, final_norm_b=w(d), pos_emb=w(cfg.max_pos, d), meta=meta)
+
+
 # ------------------------------------------------------------------------------- Medusa heads
 @dataclass
 class MedusaHeads:
