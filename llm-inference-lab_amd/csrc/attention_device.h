@@ -205,22 +205,32 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
         den += f * l_s[w * kAttnRows + r];
       }
       // the workspace is only ever touched with agent-scope RELAXED atomics (write-through stores, L2-bypassing
-      // loads): the hand-over to the last arrival then needs no fence at all (see below)
+      // loads); the hand-over to the last arrival is ordered by thread 0's release / acquire arrival below
       __hip_atomic_store(mine + i, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == 0) {
         __hip_atomic_store(mine + kAttnRows * D + r, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + kAttnRows * D + kAttnRows + r, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // No fences: an agent-scope release / acquire is a cache-wide L2 write-back / invalidate (with every thread fencing, as
-    // this code first did, 8 K / 32 K contexts took 6.34 / 8.63 ms per step; with one fencing thread per workgroup 5.66 /
-    // 7.09). The partial tiles move with relaxed agent-scope atomics instead; every thread waits for its own stores, the
-    // workgroup barrier orders them before thread 0's arrival, and the last arrival's loads depend on its poll result.
+    // Hand-over to the last arrival, in the HIP / HSA memory model: the workgroup barrier orders every thread's stores
+    // before thread 0 (workgroup scope), thread 0's arrival on the device-scope counter is an agent-scope RELEASE
+    // (cumulative over what the barrier made visible to it) and ACQUIRE (the last arrival synchronises with every
+    // earlier one), and the second barrier passes that on to the other threads of the merging workgroup. ONE thread
+    // per workgroup fences: an agent-scope fence is a cache-wide L2 write-back / invalidate on this part (with every
+    // thread fencing 8 K / 32 K contexts took 6.34 / 8.63 ms per step; this form 5.66 / 7.09). The partial tiles
+    // themselves still move with agent-scope relaxed atomics (write-through stores, L2-bypassing loads), which leaves
+    // the fences nothing to write back. Building with -DSD_ATTN_FENCE_FREE drops the release / acquire and relies on
+    // s_waitcnt + the barriers alone (gfx950 behaviour, not a memory-model guarantee: 5.6 / 6.89 ms; experiments only).
+#ifdef SD_ATTN_FENCE_FREE
     __builtin_amdgcn_s_waitcnt(0);
+    constexpr int kArrive = __ATOMIC_RELAXED;
+#else
+    constexpr int kArrive = __ATOMIC_ACQ_REL;
+#endif
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(m_s);  // LDS scratch (m_s is dead after the loop above)
     if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(a.split_cnt + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(a.split_cnt + group, 1u, kArrive, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = (old == static_cast<unsigned>(s_eff - 1));
       *flag = last ? 1u : 0u;
       if (last) __hip_atomic_store(a.split_cnt + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch

@@ -549,6 +549,9 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
     a.alias_part = 1;
     smem = gemv_smem(a.T, a.K, true);
   }
+  // rows too long to stage T of them whole (d_ff = 14336 takes 5): the chunked multi-token kernel covers the rest
+  // of 6..9 tokens — a pass may mix both kernels, they share layout, work split and epilogues
+  if (smem > kLdsLimit && !a.x_row && gemm_skinny_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return launch_gemm_skinny(a_in, epi, st);
   SD_REQUIRE(smem <= kLdsLimit, "gemv: T=%d x K=%d does not fit LDS", a.T, a.K);
   switch (epi) {
     case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(a, mask, grid, smem, st);
