@@ -140,7 +140,8 @@ int sd_kv_concat(void* out_k, void* out_v,
  *         rows [0,L)          = base
  *         rows L+j, j<n_b     = draft row of the j-th set bit of mask[b,:]
  *         rows L+n_b .. L+K-1 = 0
- *         n_b = accept_len[b]==0 ? 0 : min(popcount(mask[b,:]), accept_len[b])
+ *         n_b = accept_len[b]==0 ? 0 : min(popcount(mask[b,:]), accept_len[b] < 0 ? 1 : accept_len[b])
+ *               (a negative accept_len is invalid input; the reference loop writes one row for it, so does this)
  *   mask : device uint8[B][K] (K <= 64), accept_len : device int32[B]
  * ------------------------------------------------------------------------ */
 int sd_kv_append_masked(void* out_k, void* out_v,

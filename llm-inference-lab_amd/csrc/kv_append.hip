@@ -100,7 +100,10 @@ __global__ __launch_bounds__(kCopyThreads) void kv_append_masked_kernel(
       // slot j of the appended region takes the draft row of the j-th set mask bit,
       // for j < accept_len[b] (reference.py:146-157)
       const int j = r - L;
-      const int want = accept_len[b];
+      // (a NEGATIVE accept_len still writes the row of the first set bit there: the loop tests
+      // `accepted_count >= num_accepted` only after a write, reference.py:148-157)
+      int want = accept_len[b];
+      if (want < 0) want = 1;
       if (j < want) {
         int seen = 0, srck = -1;
         for (int k = 0; k < K; ++k) {

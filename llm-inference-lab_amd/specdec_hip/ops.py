@@ -50,12 +50,19 @@ def _require_device(name: str, *tensors: torch.Tensor) -> torch.device:
 
 
 # --------------------------------------------------------------------------- verify
+def verify_prefix_workspace(B: int, K: int, V: int, device) -> torch.Tensor:
+    """Scratch for verify_prefix_hip(..., workspace=): allocate once, reuse for every call of that shape or smaller."""
+    return torch.empty(max(_abi.load().sd_verify_prefix_workspace(B, K, V), 1), dtype=torch.uint8, device=device)
+
+
 def verify_prefix_hip(
-    logits: torch.Tensor, draft_ids: torch.Tensor, return_pred: bool = False
+    logits: torch.Tensor, draft_ids: torch.Tensor, return_pred: bool = False,
+    out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, workspace: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, ...]:
     """accept_len[B] int32, accepted_mask[B,K] uint8 (reference.py:13-56) on gfx950.
 
-    With return_pred=True also returns the argmax ids [B,K] int32.
+    With return_pred=True also returns the argmax ids [B,K] int32. `out` = (accept_len, mask) and `workspace`
+    (verify_prefix_workspace) make the call allocation-free, which is what a captured graph needs.
     """
     assert logits.dim() == 3, "logits must be 3D tensor [B][K][V]"
     assert draft_ids.dim() == 2, "draft_ids must be 2D tensor [B][K]"
@@ -72,14 +79,20 @@ def verify_prefix_hip(
     if V > 0 and logits.stride(2) != 1:
         logits = logits.contiguous()
     ids = draft_ids.contiguous()
-    accept_len = torch.empty(B, dtype=torch.int32, device=dev)
-    mask = torch.empty((B, K), dtype=torch.uint8, device=dev)
+    if out is not None:
+        accept_len, mask = out
+        assert accept_len.dtype == torch.int32 and accept_len.shape == (B,) and accept_len.is_contiguous() and accept_len.device == dev
+        assert mask.dtype == torch.uint8 and mask.shape == (B, K) and mask.is_contiguous() and mask.device == dev
+    else:
+        accept_len = torch.empty(B, dtype=torch.int32, device=dev)
+        mask = torch.empty((B, K), dtype=torch.uint8, device=dev)
     pred = torch.empty((B, K), dtype=torch.int32, device=dev) if return_pred else None
     if B == 0:
         return (accept_len, mask, pred) if return_pred else (accept_len, mask)
     lib = _abi.load()
     ws_bytes = lib.sd_verify_prefix_workspace(B, K, V)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    ws = workspace if workspace is not None else torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    assert ws.device == dev and ws.numel() >= ws_bytes, "verify_prefix: workspace too small"
     with torch.cuda.device(dev):
         rc = lib.sd_verify_prefix(
             logits.data_ptr(), sd_dtype(logits.dtype), ids.data_ptr(), sd_dtype(ids.dtype),

@@ -204,6 +204,8 @@ def config_from_hf(hf_cfg) -> ModelConfig:
         theta = rp.get("rope_theta", theta)
         if rp.get("rope_type", "default") != "default":
             rs = dict(rp)
+    if rs and rs.get("rope_type", rs.get("type", "default")) == "default":
+        rs = None   # transformers >= 5 reports the plain rope as a "default" scaling dict: same frequencies, one spelling here
     eos = hf_cfg.eos_token_id
     if isinstance(eos, (list, tuple)):
         eos = eos[0]

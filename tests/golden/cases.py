@@ -84,6 +84,7 @@ KV_CASES = [
     ("odd_dim_bf16", 2, 3, 4, 2, 7, "bf16"),
     ("empty_base", 2, 2, 0, 3, 8, "f32"),
     ("empty_new", 1, 2, 6, 0, 8, "bf16"),
+    ("negative_accept_len", 3, 2, 4, 4, 8, "f32"),   # invalid input: the reference loop still writes ONE row per negative entry
 ]
 
 
@@ -104,6 +105,9 @@ def build_kv_case(name, B, H, L, K, D, dtype, seed):
             bits[:] = 1
         mask[b] = torch.from_numpy(bits.astype(np.uint8))
         alen[b] = int(rng.integers(0, K + 1)) if b else K
+    if name == "negative_accept_len":
+        mask[:] = torch.tensor([[0, 1, 1, 0], [1, 0, 1, 1], [0, 0, 0, 0]], dtype=torch.uint8)
+        alen[:] = torch.tensor([-1, -3, -2], dtype=torch.int32)
     return base_k, base_v, new_k, new_v, mask, alen
 
 
