@@ -12,9 +12,9 @@
 //           one row with dwordx4 loads (8 bf16 / 4 f32 per lane), keeps a per-lane
 //           running (max, index), reduces over the wave with shuffles and over the
 //           4 waves through LDS, and writes one (value, index) partial.
-//   pass 2  grid B, one wave per batch row: lanes fold the nsplit partials of each
-//           k, then lane k holds match[k]; __ballot + ctz gives the longest accepted
-//           prefix without a serial scan.
+//   pass 2  grid B, one wave per batch row: lane k folds the nsplit partials of
+//           position k (independent loads: one round trip), then holds match[k];
+//           __ballot + ctz gives the longest accepted prefix without a serial scan.
 // Ties resolve to the lowest index and NaN is the maximum, as torch.argmax does.
 
 #include "common.h"
@@ -94,31 +94,27 @@ __global__ __launch_bounds__(kVerifyThreads) void verify_partial_kernel(
       if (argmax_better(v, i, bv, bi)) { bv = v; bi = i; }
     }
     const uint4* vp = reinterpret_cast<const uint4*>(rowp + body0);
-    // two vectors in flight per lane per trip
-    int j = threadIdx.x;
-    for (; j + kVerifyThreads < nvec; j += 2 * kVerifyThreads) {
-      const uint4 a = vp[j];
-      const uint4 c = vp[j + kVerifyThreads];
-      const int ia = body0 + j * VT::N;
-      const int ic = ia + kVerifyThreads * VT::N;
+    // four independent 16-byte loads in flight per lane per trip (16 KiB per workgroup): a chunk of the default
+    // size is ONE memory round trip; the compares run after all four have been issued
+    constexpr int kInFlight = 4;
+    for (int j0 = 0; j0 < nvec; j0 += kInFlight * kVerifyThreads) {
+      uint4 q[kInFlight];
 #pragma unroll
-      for (int e = 0; e < VT::N; ++e) {
-        const float v = VT::get(a, e);
-        if (argmax_better(v, ia + e, bv, bi)) { bv = v; bi = ia + e; }
+      for (int u = 0; u < kInFlight; ++u) {
+        const int j = j0 + u * kVerifyThreads + static_cast<int>(threadIdx.x);
+        q[u] = (j < nvec) ? vp[j] : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int e = 0; e < VT::N; ++e) {
-        const float v = VT::get(c, e);
-        if (argmax_better(v, ic + e, bv, bi)) { bv = v; bi = ic + e; }
-      }
-    }
-    for (; j < nvec; j += kVerifyThreads) {
-      const uint4 a = vp[j];
-      const int ia = body0 + j * VT::N;
+      for (int u = 0; u < kInFlight; ++u) {
+        const int j = j0 + u * kVerifyThreads + static_cast<int>(threadIdx.x);
+        if (j < nvec) {
+          const int ia = body0 + j * VT::N;
 #pragma unroll
-      for (int e = 0; e < VT::N; ++e) {
-        const float v = VT::get(a, e);
-        if (argmax_better(v, ia + e, bv, bi)) { bv = v; bi = ia + e; }
+          for (int e = 0; e < VT::N; ++e) {
+            const float v = VT::get(q[u], e);
+            if (argmax_better(v, ia + e, bv, bi)) { bv = v; bi = ia + e; }
+          }
+        }
       }
     }
     {
@@ -146,7 +142,10 @@ __global__ __launch_bounds__(kVerifyThreads) void verify_partial_kernel(
   }
 }
 
-// pass 2: one wave per batch row
+// pass 2: one wave per batch row. Lane k folds the nsplit partials of position k itself — the loads of a lane are
+// independent of each other and of the other lanes', so the whole fold is one memory round trip (a wave-wide reduce
+// per position, one after the other, cost a dependent L2 miss per k: +1 us per draft token) — then holds
+// match[k]; __ballot + ctz gives the longest accepted prefix without a serial scan.
 template <typename IdT>
 __global__ __launch_bounds__(kWave) void verify_finalize_kernel(
     const float* __restrict__ ws_val, const int* __restrict__ ws_idx, int nsplit,
@@ -159,29 +158,34 @@ __global__ __launch_bounds__(kWave) void verify_finalize_kernel(
   for (int k0 = 0; k0 < K; k0 += kWave) {
     const int kn = min(kWave, K - k0);
     int my_pred = -1;
-    for (int kk = 0; kk < kn; ++kk) {
-      const int row = b * K + k0 + kk;
-      float v = -INFINITY;
-      int i = 0x7fffffff;
-      for (int s = lane; s < nsplit; s += kWave) {
-        const float sv = ws_val[row * nsplit + s];
-        const int si = ws_idx[row * nsplit + s];
-        if (argmax_better(sv, si, v, i)) { v = sv; i = si; }
-      }
-      wave_reduce_argmax(v, i);
-      if (lane == kk) my_pred = i;
-    }
     bool match = false;
     if (lane < kn) {
-      const long long want = static_cast<long long>(ids[b * K + k0 + lane]);
+      const size_t row = static_cast<size_t>(b) * K + k0 + lane;
+      const long long want = static_cast<long long>(ids[row]);
+      float v = -INFINITY;
+      int i = 0x7fffffff;
+      for (int s0 = 0; s0 < nsplit; s0 += 8) {       // 8 partials (16 loads) in flight
+        float sv[8];
+        int si[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = (s0 + u < nsplit) ? s0 + u : nsplit - 1;
+          sv[u] = ws_val[row * nsplit + s];
+          si[u] = ws_idx[row * nsplit + s];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < nsplit && argmax_better(sv[u], si[u], v, i)) { v = sv[u]; i = si[u]; }
+      }
+      my_pred = i;
       match = (static_cast<long long>(my_pred) == want);
-      if (pred_out) pred_out[b * K + k0 + lane] = my_pred;
+      if (pred_out) pred_out[row] = my_pred;
     }
     const unsigned long long m = __ballot(match);
     const unsigned long long valid = (kn == 64) ? ~0ull : ((1ull << kn) - 1ull);
     const unsigned long long miss = (~m) & valid;
     const int run = open ? (miss ? __builtin_ctzll(miss) : kn) : 0;
-    if (lane < kn) mask[b * K + k0 + lane] = (lane < run) ? 1 : 0;
+    if (lane < kn) mask[static_cast<size_t>(b) * K + k0 + lane] = (lane < run) ? 1 : 0;
     accepted += run;
     if (run < kn) open = false;
   }
