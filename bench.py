@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--target", default="llama-3.2-3b")
     ap.add_argument("--draft", default="llama-3.2-1b")
     ap.add_argument("--flip", type=float, default=0.2, help="fraction of tokens whose draft successor differs")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=6, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2,
+                    help="steps per timed repeat of the CPU baseline leg (1 warm-up step + 3 repeats); 0 disables the leg")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: both models stream an OCP e4m3 copy of their Linear weights (per-row scales, bf16 activations and "
@@ -99,21 +100,53 @@ def prompts_for(rank, batch, vocab):
     return out
 
 
-def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows, weight_dtype="bf16"):
-    """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample.
-    Returns the baseline dict and whether the GPU emitted the same tokens on those steps."""
+def cpu_model_string() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
+def cpu_threads():
+    """(threads to use, how that number was found): the cgroup CPU quota when the box enforces one (a 1-GPU share of a
+    multi-GPU host), else the affinity mask; SPECDEC_CPU_THREADS overrides."""
+    if os.environ.get("SPECDEC_CPU_THREADS"):
+        return int(os.environ["SPECDEC_CPU_THREADS"]), "SPECDEC_CPU_THREADS"
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            return max(1, min(visible, int(int(quota) / int(period)))), f"cgroup cpu.max {quota}/{period} (of {visible} visible)"
+    except (OSError, ValueError):
+        pass
+    # no quota visible: a 1-GPU box of this pool is given a 16-CPU share of the host whatever the mask says
+    return min(visible, 16), f"min(affinity mask {visible}, 16-CPU share of a 1-GPU box)"
+
+
+def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=2, repeats=3):
+    """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample (SURVEY section 8d protocol:
+    one warm-up, >= 3 timed repeats, median; CPU model and thread count stated).
+      L0 = 32 (the GPU run's prompt 0): ONE run of 1 + repeats * seg_steps steps; step 1 is the warm-up, every following
+        segment of `seg_steps` steps is one timed repeat (tokens of the segment / its wall time); all of its tokens are
+        compared with what the GPU emitted for that prompt;
+      L0 = 128 (a second synthetic prompt, CPU only): 1 warm-up step + `repeats` single-step repeats.
+    Returns the baseline dict and whether the GPU emitted the same tokens on the L0 = 32 steps."""
     from oracle.model_ref import OracleLM
     from oracle.pipeline_ref import OraclePipeline
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    # a 1-GPU box gives this job a 16-CPU share whatever the affinity mask says
-    cores = int(os.environ.get("SPECDEC_CPU_THREADS", min(cores, 16)))
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads, copying weights to the host")
+    threads, how = cpu_threads()
+    torch.set_num_threads(threads)
+    log(f"cpu_baseline: {threads} threads [{how}] on {cpu_model_string()}; copying weights to the host")
     d_cpu, t_cpu = drf.to("cpu"), tgt.to("cpu")
     if weight_dtype == "fp8":
         from oracle import fp8_ref
@@ -121,20 +154,37 @@ def cpu_baseline(drf, tgt, prompts, k, n_steps, gpu_rows, weight_dtype="bf16"):
         d_cpu, t_cpu = fp8_ref.dequantized(d_cpu), fp8_ref.dequantized(t_cpu)
     base, draft = OracleLM(t_cpu, "bf16"), OracleLM(d_cpu, "bf16")
     pipe = OraclePipeline(base, draft, k=k, eos_token_id=tgt.config.eos_token_id, reprefill=True)
-    # warm: materialise the fp32 weight copies outside the timed region
+    # materialise the fp32 weight copies outside the timed region
     base.forward(torch.tensor([prompts[0][:2]]))
     draft.forward(torch.tensor([prompts[0][:2]]))
-    log(f"cpu_baseline: timing {n_steps} reference-faithful step(s) on the host")
-    t0 = time.time()
-    res = pipe.generate_batch([prompts[0]], max_tokens=10 ** 6, max_steps=n_steps)[0]
-    dt = time.time() - t0
+
+    def run(prompt, seg):
+        n_steps = 1 + repeats * seg
+        marks = [(time.time(), 0)]
+        res = pipe.generate_batch([prompt], max_tokens=10 ** 6, max_steps=n_steps, step_log=marks)[0]
+        rates = []
+        for r in range(repeats):
+            (t0, n0), (t1, n1) = marks[1 + r * seg], marks[1 + (r + 1) * seg]
+            rates.append((n1 - n0) / (t1 - t0) if t1 > t0 else 0.0)
+        return res, sorted(rates)[len(rates) // 2], rates, marks[-1][0] - marks[0][0]
+
+    log(f"cpu_baseline: L0={PROMPT_LEN}: 1 warm-up step + {repeats} x {seg_steps} timed steps of the reference-faithful loop")
+    res, med, rates, wall = run(prompts[0], seg_steps)
     n = len(res["generated_tokens"])
     same = gpu_rows[0][:n] == res["generated_tokens"]
+    g = torch.Generator().manual_seed(1234 + 10007)
+    long_prompt = torch.randint(4, tgt.config.vocab, (128,), generator=g, dtype=torch.int64).tolist()
+    log(f"cpu_baseline: L0=128: 1 warm-up step + {repeats} x 1 timed step")
+    res_l, med_l, rates_l, wall_l = run(long_prompt, 1)
     return {
-        "value": n / dt if dt > 0 else 0.0, "unit": "tokens/s", "cores": cores, "kind": "port",
-        "sample": f"{res['steps']} steps of prompt 0 ({n} tokens, {dt:.1f} s): reference-faithful loop, "
-                  f"2K full-prefix forwards per step, bf16-rounded weights/activations with fp32 accumulation",
+        "value": med, "unit": "tokens/s", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model_string(), "threads_source": how,
+        "sample": f"prompt 0 (L0={PROMPT_LEN}), reference-faithful loop (2K full-prefix forwards per step, bf16-rounded weights / activations, fp32 "
+                  f"accumulation): 1 warm-up step, then {repeats} repeats of {seg_steps} steps each, median of the per-repeat rates "
+                  f"{[round(r, 3) for r in rates]} tokens/s ({n} tokens, {wall:.1f} s in all)",
         "acceptance_rate": res["acceptance_rate"],
+        "L0_128": {"value": med_l, "unit": "tokens/s", "rates": [round(r, 3) for r in rates_l],
+                   "sample": f"a 128-token synthetic prompt, 1 warm-up step + {repeats} x 1 step ({wall_l:.1f} s)"},
     }, bool(same)
 
 
@@ -188,6 +238,70 @@ def bind_to_gpu_numa(local: int, ranks_on_host: int) -> dict:
     except (AttributeError, OSError, ValueError):
         pass
     return info
+
+
+def lib_sha256() -> str:
+    import hashlib
+
+    from specdec_hip import _abi
+
+    return hashlib.sha256(_abi.lib_path().read_bytes()).hexdigest()
+
+
+def roofline_leg(sess, B, K, wd, self_draft):
+    """Every weight-streaming GEMV of the step timed live (sd_model_probe_gemv: HIP events on the launch stream, round-robin
+    over the layers so the weights come from HBM); `roofline` describes the one with the most time per step —
+    launches per step x average launch time — priced at its algorithmic bytes (N*K*sizeof(weight)) over that time."""
+    st = torch.cuda.Stream()
+    tm = sess.rt["target"]
+    dm = None if self_draft else sess.rt["draft"]
+    Tt = min(B * (K + 1), tm.pass_tokens)
+    cand = []   # (label, model, which, T, launches per step)
+    names = {tm.PROBE_O: ("o_proj", "EPI_RESID"), tm.PROBE_GATE_UP: ("norm+gate/up+SwiGLU", "EPI_SWIGLU"), tm.PROBE_DOWN: ("down", "EPI_RESID"),
+             tm.PROBE_LM_HEAD: ("norm+lm_head+argmax", "EPI_ARGMAX")}
+    for which in (tm.PROBE_O, tm.PROBE_GATE_UP, tm.PROBE_DOWN, tm.PROBE_LM_HEAD):
+        n = 1 if which == tm.PROBE_LM_HEAD else tm.cfg.n_layers
+        cand.append(("target", tm, which, Tt, n))
+        if dm is not None:
+            nd = (1 if which == dm.PROBE_LM_HEAD else dm.cfg.n_layers)
+            cand.append(("draft", dm, which, min(B, dm.pass_tokens), nd * (K - 1)))       # draft forwards 2..K: one token per row
+            cand.append(("draft", dm, which, min(2 * B, dm.pass_tokens), nd))             # draft forward 1: (prev, last)
+    rows = []
+    for who, m, which, T, n in cand:
+        u, nb = m.probe_gemv(which, T=T, iters=200 if which != m.PROBE_LM_HEAD else 60, stream=st)
+        kname = "gemv_mfma_kernel" if T <= 9 else "gemm_skinny_kernel"
+        rows.append({"kernel": f"{kname}<{names[which][1]}> ({who} {names[which][0]}, {T} token{'s' if T > 1 else ''})", "who": who, "which": which,
+                     "T": T, "launches_per_step": n, "avg_launch_us": u, "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9,
+                     "us_per_step": n * u})
+    top = max(rows, key=lambda r: r["us_per_step"])
+    ach = top["GBps"]
+    roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+            "frac": ach * 1e9 / HBM_PEAK_BPS, "traffic": None, "bytes_per_launch": top["bytes_per_launch"],
+            "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"], "us_per_step": top["us_per_step"],
+            "selection": "the GEMV with the largest (launches per step x average launch time), all timed in this run"}
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE x2 on
+    # gfx950; profiles/summarize.py): counters cannot be read from inside this process, so the figure comes from the
+    # committed summary — and only when that summary was taken with THIS build of the library (content hash)
+    pmc = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+    epi = {tm.PROBE_O: 1, tm.PROBE_GATE_UP: 2, tm.PROBE_DOWN: 1, tm.PROBE_LM_HEAD: 4}[top["which"]]
+    tt = next(t for t in (1, 2, 3, 5, 9) if top["T"] <= t) if top["T"] <= 9 else None
+    if os.path.exists(pmc) and tt is not None and wd == "bf16":
+        with open(pmc) as f:
+            tj = json.load(f)
+        meta = tj.get("_meta", {})
+        if meta.get("lib_sha256") != lib_sha256():
+            roof["traffic_note"] = "profiles/round2_pmc_traffic.json was taken with another build of libspecdec_hip.so: not quoted"
+        elif meta.get("workload") != f"{sess.pipe.base_lm.model_name}+{'' if self_draft else sess.pipe.draft_lm.model_name} K={K} B={B}":
+            roof["traffic_note"] = f"profiles/round2_pmc_traffic.json is for {meta.get('workload')!r}: not quoted"
+        else:
+            # gate/up and down differ in bytes per launch: pick the entry of this epilogue and token bucket whose bytes are nearest
+            ks = [(k, v) for k, v in tj.items() if k.startswith(f"gemv_mfma_kernel<{epi}, false, {tt}, false")]
+            if ks:
+                k_, t = min(ks, key=lambda kv: abs(kv[1]["hbm_bytes_per_launch"] - top["bytes_per_launch"]))
+                roof["traffic"] = t["hbm_bytes_per_launch"]
+                roof["traffic_source"] = f"profiles/round2_pmc_traffic.json [{k_}] (rocprofv3 --pmc passes of bench.py, same library build)"
+    roof["other_kernels"] = {r["kernel"]: {k: r[k] for k in ("avg_launch_us", "GBps", "launches_per_step", "us_per_step")} for r in rows if r is not top}
+    return roof
 
 
 def dry_run(args, world, rank):
@@ -360,41 +474,11 @@ def main():
     log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} tok/s")
     # ---- roofline of the dominant kernel, timed live with HIP events --------------------
     if not args.no_probe:
-        tm = sess.rt["target"]
-        st = torch.cuda.Stream()
-        usec, nbytes = tm.probe_gemv(tm.PROBE_GATE_UP, T=min(B * (K + 1), tm.pass_tokens), iters=280, stream=st)
-        ach = nbytes / (usec * 1e-6) / 1e9
-        Tp = min(B * (K + 1), tm.pass_tokens)
-        kname = "gemv_mfma_kernel<EPI_SWIGLU>" if Tp <= 9 else f"gemm_skinny_kernel<EPI_SWIGLU, {(Tp + 15) // 16}>"
-        out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (target norm+gate/up+SwiGLU, {Tp} tokens)",
-                           "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK_BPS,
-                           "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": usec}
-        # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
-        # runs, FETCH_SIZE x2 on gfx950): counters cannot be read from inside this process, so the
-        # figure comes from the committed summary of the same command (profiles/summarize.py)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-        if os.path.exists(pmc) and B * (K + 1) == 5 and wd == "bf16" and args.target == "llama-3.2-3b":
-            with open(pmc) as f:
-                tj = json.load(f)
-                t = next((v for k, v in tj.items() if k.startswith("gemv_mfma_kernel<2, false, 5, false")), None)
-            if t:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc passes of bench.py)"
-        others = {}
-        for name, which, T in (("target_lm_head", tm.PROBE_LM_HEAD, min(B * (K + 1), tm.pass_tokens)),
-                               ("target_down", tm.PROBE_DOWN, min(B * (K + 1), tm.pass_tokens)),
-                               ("target_o_proj", tm.PROBE_O, min(B * (K + 1), tm.pass_tokens))):
-            u, nb = tm.probe_gemv(which, T=T, iters=140, stream=st)
-            others[name] = {"avg_launch_us": u, "GBps": nb / (u * 1e-6) / 1e9}
-        dmod = sess.rt["draft"]
-        for name, which in (("draft_gate_up", dmod.PROBE_GATE_UP), ("draft_lm_head", dmod.PROBE_LM_HEAD)):
-            u, nb = dmod.probe_gemv(which, T=B, iters=160, stream=st)
-            others[name] = {"avg_launch_us": u, "GBps": nb / (u * 1e-6) / 1e9}
-        out["roofline"]["other_kernels"] = others
+        out["roofline"] = roofline_leg(sess, B, K, wd, medusa or heads is not None)
     # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------------------------
     if world == 1 and args.cpu_baseline_steps > 0:
         gpu_rows = [list(r.generated) for r in sess.rows]
-        cb, same = cpu_baseline(drf, tgt, prompts, K, args.cpu_baseline_steps, gpu_rows, wd)
+        cb, same = cpu_baseline(drf, tgt, prompts, K, gpu_rows, wd, seg_steps=args.cpu_baseline_steps)
         out["cpu_baseline"] = cb
         out["parity_with_cpu_sample"] = same
         out["speedup_vs_cpu_baseline"] = value / cb["value"] if cb["value"] > 0 else None

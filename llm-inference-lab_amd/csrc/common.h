@@ -68,6 +68,25 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
   return *reinterpret_cast<uint16_t*>(&h);
 }
 
+// Two bf16 values of one 32-bit word <-> two floats, on the packed-math VALU path of gfx950: the unpack is two bit
+// operations, the arithmetic in between is v_pk_mul_f32 / v_pk_fma_f32 (two lanes of fp32 per instruction) and the
+// re-pack is ONE v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN) — half the instructions of the scalar
+// sequence. The normalisation fused into the staging of x is VALU-bound (every workgroup normalises all T x K
+// activations), so this is where the instruction count matters.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t bf16x2_unpack(uint32_t u) { return f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t bf16x2_pack(f32x2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
+// HF LlamaRMSNorm on a pair: weight * (x * rstd).to(bf16), rounded to bf16 again
+__device__ __forceinline__ uint32_t rmsnorm_pair(uint32_t x, float rs, uint32_t w) {
+  const f32x2_t xn = bf16x2_unpack(bf16x2_pack(bf16x2_unpack(x) * rs));
+  return bf16x2_pack(xn * bf16x2_unpack(w));
+}
+// GPT-2 LayerNorm on a pair: ((x - mean) * rstd) * w + b in fp32, rounded once
+__device__ __forceinline__ uint32_t layernorm_pair(uint32_t x, float mean, float rs, uint32_t w, uint32_t b) {
+  return bf16x2_pack((bf16x2_unpack(x) - mean) * rs * bf16x2_unpack(w) + bf16x2_unpack(b));
+}
+
 // Sum over the 64 lanes, result in every lane. Data-parallel-primitive moves on the VALU (v_add_f32 with a DPP
 // operand), not __shfl_xor: that lowers to ds_bpermute_b32, which occupies the LDS pipe — with 16 waves per CU
 // doing 2 x T reductions in the norm prologue of every GEMV the LDS pipe, not HBM, set the prologue's length

@@ -38,6 +38,7 @@ struct sd_model {
   int32_t* probe_pos = nullptr;  // [1] zero: position base of the QKV probe
   float* attn_ws = nullptr;      // split-KV partial tiles (attention.hip)
   unsigned* attn_cnt = nullptr;  // arrival counters, zero between launches
+  float* xstat = nullptr;    // [2][128][256]: row statistics handed from an EPI_RESID launch to the next norm-fused one (> 9 tokens)
   float* part_val = nullptr; // [64][512]
   int small_t = sd::kGemvMaxT; // tokens per pass of gemv.hip for this model's widest activation row (<= 9)
   int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
@@ -65,6 +66,7 @@ static size_t workspace_bytes(const sd_model_config& c) {
   n += align_up(T * c.d_ff * 2, 256);
   n += align_up(T * kMaxPartials * 4, 256) * 2;
   n += align_up(attention_split_ws_bytes(c.head_dim), 256);
+  n += align_up(sizeof(float) * 2 * kStatPlane, 256);
   return n + 256;
 }
 
@@ -95,6 +97,18 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   if (int rc = launch_embed(e, st)) return rc;
 
   const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+  // > 9 tokens: the launch that writes the residual stream hands its row statistics to the launch that normalises it
+  const float* stat_in = nullptr;
+  int stat_n = 0;
+  auto publish = [&](GemvArgs& prod) {      // prod: an EPI_RESID launch about to be issued
+    stat_in = nullptr;
+    if (m->xstat && gemm_resid_publishes_stats(prod)) {
+      prod.xstat_out = m->xstat;
+      stat_in = m->xstat;
+      int ppw = 1;
+      stat_n = gemv_grid(prod, &ppw);
+    }
+  };
   for (int l = 0; l < c.n_layers; ++l) {
     const sd_layer_weights& w = m->layers[l];
     uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
@@ -134,6 +148,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     a1.rope_sin = llama ? c.rope_sin : nullptr;
     a1.k_cache = kc;
     a1.v_cache = vc;
+    a1.xstat_in = stat_in;
+    a1.xstat_n = stat_n;
     if (int rc = launch_gemv(a1, EPI_QKV_ROPE, st)) return rc;
 
     // 2. attention of the Mc new positions over the appended cache
@@ -184,6 +200,9 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     a4.norm_eps = c.norm_eps;
     a4.out = m->act;
     a4.out_stride = ff;
+    publish(a3);
+    a4.xstat_in = stat_in;
+    a4.xstat_n = stat_n;
     if (llama) {
       a4.N = 2 * ff;
       a4.n_pairs = ff;
@@ -209,6 +228,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     a5.prologue = PRO_NONE;
     a5.out = m->x;
     a5.out_stride = d;
+    publish(a5);
     if (int rc = launch_gemv(a5, EPI_RESID, st)) return rc;
   }
   if (skip_head) return 0;
@@ -235,6 +255,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   h.out_dtype = logits_dtype;
   h.part_val = m->part_val;
   h.part_idx = m->part_idx;
+  h.xstat_in = stat_in;
+  h.xstat_n = stat_n;
   int ks = 1;
   m->head_grid = gemv_grid(h, &ks);
   if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
@@ -411,6 +433,8 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->attn_ws = reinterpret_cast<float*>(p);
   m->attn_cnt = reinterpret_cast<unsigned*>(p + static_cast<size_t>(kAttnSplitSlots) * 16 * (c.head_dim + 2) * sizeof(float));
   p += align_up(attention_split_ws_bytes(c.head_dim), 256);
+  m->xstat = reinterpret_cast<float*>(p);
+  p += align_up(sizeof(float) * 2 * kStatPlane, 256);
   SD_HIP_CHECK(hipMemset(m->attn_cnt, 0, kAttnSplitSlots * sizeof(unsigned)));
   m->probe_pos = reinterpret_cast<int32_t*>(m->attn_cnt);   // a zero word (the counters rest at zero between launches)
   return 0;
@@ -447,6 +471,9 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
   }
   // SPECDEC_PROBE_HOT=n: cycle over n layers only (n=1: the same matrix every launch, i.e. cache-resident weights)
   const int hot = getenv("SPECDEC_PROBE_HOT") ? atoi(getenv("SPECDEC_PROBE_HOT")) : 0;
+  // > 9 tokens: as in the forward, the norm-fused launches read the row statistics the previous launch left, and the
+  // residual launches leave them (SPECDEC_PROBE_NO_XSTAT=1: every launch computes its own, as for the first layer)
+  const bool use_xstat = T > kGemvMaxT && T <= 64 && !getenv("SPECDEC_PROBE_NO_XSTAT");
   auto launch = [&](int l) -> int {
     if (hot > 0) l %= hot;
     const sd_layer_weights& w = m->layers[l % c.n_layers];
@@ -461,6 +488,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     g.M = T;
     g.out_dtype = SD_BF16;
     g.norm_eps = c.norm_eps;
+    if (use_xstat && (which == 0 || which == 2 || which == 4)) { g.xstat_in = m->xstat; g.xstat_n = 256; }
     switch (which) {
       case 0: {  // norm + QKV projection + RoPE + in-place KV append (row 0 of the cache, positions 0..T-1)
         const int Hkv = c.n_kv_heads;
@@ -476,6 +504,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
       case 1:  // attention output projection + residual
         g.W = m->mat(4 * li + 1, w.wo); g.bias = w.bo; g.N = d; g.K = Hq * D; g.n_pairs = d / 2;
         g.x = m->attn; g.x_stride = Hq * D; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
+        if (use_xstat && gemm_resid_publishes_stats(g)) g.xstat_out = m->xstat;
         return launch_gemv(g, EPI_RESID, st);
       case 2:  // norm + gate/up + SwiGLU (GELU for GPT-2)
         g.W = m->mat(4 * li + 2, w.w_up); g.bias = w.b_up; g.K = d; g.x = m->x; g.x_stride = d;
@@ -487,6 +516,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
       case 3:  // down projection + residual
         g.W = m->mat(4 * li + 3, w.w_down); g.bias = w.b_down; g.N = d; g.K = ff; g.n_pairs = d / 2;
         g.x = m->act; g.x_stride = ff; g.prologue = PRO_NONE; g.out = m->x; g.out_stride = d;
+        if (use_xstat && gemm_resid_publishes_stats(g)) g.xstat_out = m->xstat;
         return launch_gemv(g, EPI_RESID, st);
       case 4:  // final norm + lm_head + fused argmax
         g.W = m->mat(4 * c.n_layers, c.lm_head); g.N = c.vocab; g.K = d; g.n_pairs = (c.vocab + 1) / 2; g.x = m->x; g.x_stride = d;
@@ -528,9 +558,9 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     int n = 0;
     for (int b = 0; b < 256; ++b)
       if (h[b * 8]) { t0 = h[b * 8] < t0 ? h[b * 8] : t0; ++n; }
-    static const char* names[7] = {"entry", "issued", "staged", "mfma_done", "reduced", "epilogue", "end"};  // gemm_skinny: issued = +statistics, staged = first chunk
+    static const char* names[8] = {"entry", "issued", "staged", "mfma_done", "reduced", "epilogue", "end", "(stats)"};  // gemm_pipe: issued = first loads issued, (stats) = statistics done, staged = chunk 0
     fprintf(stderr, "[timeline which=%d T=%d] %d workgroups, us from first entry (min / mean / max):\n", which, T, n);
-    for (int s = 0; s < 7; ++s) {
+    for (int s = 0; s < 8; ++s) {
       double mn = 1e30, mx = 0, sum = 0;
       for (int b = 0; b < 256; ++b) {
         if (!h[b * 8]) continue;

@@ -505,6 +505,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArg
   int best_i[TG];
 #pragma unroll
   for (int q = 0; q < TG; ++q) { best_v[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+  float st_sq[TG] = {}, st_sum[TG] = {};   // row statistics of the new residual values (xstat_out)
   for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
     const int tsl = it >> 7, jp = (it >> 4) & 7, tl = it & 15;
     const int p = p_lo + tsl * tile_pairs + jp;
@@ -521,17 +522,240 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArg
             y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
             y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
           }
-          epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
+          if constexpr (EPI == EPI_RESID) epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q], false, 0u, &st_sq[q], &st_sum[q]);
+          else epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
         }
       }
     }
+  }
+  if constexpr (EPI == EPI_RESID)
+    if (a.xstat_out) resid_stats_publish<TG>(a, st_sq, st_sum, part + static_cast<size_t>(kGemvWaves) * TG * 256, tid);   // scratch after the partials
+}
+
+// ------------------------------------------------------------------------------
+// Wave-private operand staging for the same shapes (un-normalised, single round of tiles: out / down projections)
+// at 17..64 tokens. With N = d_model rows over 256 workgroups a CU owns ~12 weight rows but needs ALL of x: per CU the
+// activations (T x K x 2 B) outweigh the weights 2-3x, and each x element is consumed by exactly ONE wave (the one
+// that owns its K slice). So there is nothing to share through a workgroup-wide staged chunk — the two workgroup
+// barriers and the L2 round trip per chunk of the staged kernel were pure cost (13.5 us for the 3B out-projection at
+// 40 tokens = 0.17 of the HBM roofline). Here every wave runs alone until the final K-slice reduction:
+//   * its K slice is walked in sub-slices of W = 64 (32 above 48 tokens) columns; the x rows of a sub-slice are
+//     loaded with full 16-byte lanes (8 or 16 token rows x 128 / 64 contiguous bytes per wave-instruction, not the
+//     16 x 64-byte gather of the direct variant), written to the wave's OWN LDS region (no workgroup barrier: DS
+//     operations of a wave execute in order) and read back as MFMA B fragments;
+//   * two register sets (A / B) alternate, each holding the weights and the x rows of one sub-slice: while one is
+//     consumed the other is in flight (16 waves x ~7 KiB per CU);
+//   * one barrier in the whole kernel, before the K-slice partials are summed.
+// ------------------------------------------------------------------------------
+template <int TG>
+struct SliceCfg {
+  static constexpr int W = (TG <= 3) ? 64 : 32;          // columns per sub-slice
+  static constexpr int RPI = 1024 / (W * 2);             // token rows per wave-wide 16-byte load instruction
+  static constexpr int NX = 16 * TG / RPI;               // x load instructions per sub-slice
+  static constexpr int NWS = W / 32;                     // weight steps per sub-slice
+  static constexpr int XP = W + kXPad;                   // padded row length in LDS (elements)
+  static constexpr int REGION = 16 * TG * XP * 2;        // bytes of a wave's private x buffer
+};
+
+template <int EPI, int TG>
+__global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs a) {
+  using C = SliceCfg<TG>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = a.K, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  uint16_t* xw = reinterpret_cast<uint16_t*>(smem + static_cast<size_t>(wave) * C::REGION);   // this wave's [16 TG][W + pad]
+  float* part = reinterpret_cast<float*>(smem + static_cast<size_t>(kGemvWaves) * C::REGION);  // [16 waves][TG][16][16]
+  const int ksplit = a.ksplit;
+  const int tiles_per_round = kGemvWaves / ksplit;
+  const int kpart = wave & (ksplit - 1);
+  const int tslot = wave / ksplit;
+  const int k_begin = kpart * a.kw;
+  const int nsub = a.kw / C::W;                          // sub-slices of this wave (launcher: kw % W == 0)
+  const uint16_t* Wt = static_cast<const uint16_t*>(a.W);
+  const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
+  const int p_hi = min(p_lo + a.ppw, a.n_pairs);
+  const int tile_pairs = a.tile_pairs;
+  const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;   // <= tiles_per_round (launcher)
+  const bool valid = tslot < n_tiles;
+
+  // A fragment address: base + step * wstride + lane_off (as gemv.hip); waves without a tile read tile 0 (L2 hits)
+  int wstride = 32;
+  unsigned lane_off = 0;
+  const uint16_t* wbase;
+  {
+    const int tile = valid ? tslot : 0;
+    const int p0 = p_lo + tile * tile_pairs;
+    if (a.packed) {
+      int np = min(tile_pairs, p_hi - p0);
+      if (np < 1) np = 1;
+      int jp = n & 7, second = n >> 3;
+      if (jp >= np) { jp = 0; second = 0; }
+      wstride = np * 64;
+      lane_off = static_cast<unsigned>((g * 2 * np + second * np + jp) * 8);
+      wbase = Wt + static_cast<size_t>(p0) * 2 * K + static_cast<size_t>(k_begin >> 5) * wstride;
+    } else {
+      int p = p0 + (n & 7);
+      int second = n >> 3;
+      if ((n & 7) >= tile_pairs || p >= p_hi) { p = min(p0, p_hi - 1); second = 0; }
+      int r0, r1;
+      pair_rows<EPI>(a, p, r0, r1);
+      int r = second ? r1 : r0;
+      if (r >= a.N) r = r0;
+      lane_off = static_cast<unsigned>(r) * static_cast<unsigned>(K) + static_cast<unsigned>(g * 8);
+      wbase = Wt + k_begin;
+    }
+  }
+  // x rows of a sub-slice: load instruction i covers token rows i*RPI .. i*RPI + RPI-1; lane -> (row, 16-byte chunk)
+  constexpr int CPR = C::W / 8;                           // chunks per row
+  const int xrow_in = lane / CPR, xchunk = lane % CPR;
+  const uint16_t* xin = static_cast<const uint16_t*>(a.x) + k_begin + xchunk * 8;
+  unsigned xoff[C::NX];                                   // element offset of this lane's row for load instruction i
+#pragma unroll
+  for (int i = 0; i < C::NX; ++i) {
+    const int t = i * C::RPI + xrow_in;
+    xoff[i] = static_cast<unsigned>(t < T ? t : T - 1) * static_cast<unsigned>(a.x_stride);
+  }
+  const int lds_w = xrow_in * C::XP + xchunk * 8;         // + i * RPI * XP
+  int lds_r[TG];                                          // B fragment of token 16 q + n, k-group g (+ step * 32)
+#pragma unroll
+  for (int q = 0; q < TG; ++q) lds_r[q] = (16 * q + n) * C::XP + g * 8;
+
+  struct Set { u32x4 w[C::NWS]; u32x4 x[C::NX]; };
+  Set A, B;
+  auto issue = [&](Set& s, int c) {                      // unconditional: sub-slices past the end re-read the last one
+    const int cc = c < nsub ? c : nsub - 1;
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) s.x[i] = *reinterpret_cast<const u32x4*>(xin + xoff[i] + cc * C::W);
+#pragma unroll
+    for (int j = 0; j < C::NWS; ++j)
+      s.w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + static_cast<size_t>(cc * C::NWS + j) * wstride + lane_off));
+  };
+  f32x4_t acc[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto consume = [&](Set& s, int c) {
+    if (c >= nsub) return;                                 // wave-uniform
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) *reinterpret_cast<u32x4*>(xw + lds_w + i * C::RPI * C::XP) = s.x[i];
+#pragma unroll
+    for (int j = 0; j < C::NWS; ++j)
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xw + lds_r[q] + j * 32);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, s.w[j]), __builtin_bit_cast(bf16x8_t, xb), acc[q], 0, 0, 0);
+      }
+  };
+  // The loads of the OTHER set must be in flight while one set is consumed. Left alone, the machine scheduler sinks
+  // every load to its first use (register pressure heuristic) and the loop degenerates to issue -> s_waitcnt vmcnt(0)
+  // -> consume with ONE set live; a scheduling barrier after each issue pins the order, and the waits become counted
+  // (vmcnt = loads of the younger set).
+#define SD_PIN_ORDER()                    \
+  do {                                    \
+    asm volatile("" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+  issue(A, 0);
+  SD_PIN_ORDER();
+  for (int c = 0; c < nsub; c += 2) {
+    issue(B, c + 1);
+    SD_PIN_ORDER();
+    consume(A, c);
+    SD_PIN_ORDER();
+    issue(A, c + 2);
+    SD_PIN_ORDER();
+    consume(B, c + 1);
+    SD_PIN_ORDER();
+  }
+#undef SD_PIN_ORDER
+
+  float* slot = part + static_cast<size_t>(wave) * TG * 256;
+#pragma unroll
+  for (int q = 0; q < TG; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slot[q * 256 + (4 * g + e) * 16 + n] = valid ? acc[q][e] : 0.f;
+  __syncthreads();
+  float best_v[TG];
+  int best_i[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) { best_v[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+  float st_sq[TG] = {}, st_sum[TG] = {};   // row statistics of the new residual values (xstat_out)
+  for (int it = tid; it < tiles_per_round * 128; it += kGemvThreads) {
+    const int tsl = it >> 7, jp = (it >> 4) & 7, tl = it & 15;
+    const int p = p_lo + tsl * tile_pairs + jp;
+    if (tsl < n_tiles && jp < tile_pairs && p < p_hi) {
+      int r0, r1;
+      pair_rows<EPI>(a, p, r0, r1);
+      uint32_t oldv[TG];
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+          const int t = 16 * q + tl;
+          oldv[q] = *reinterpret_cast<const uint32_t*>(static_cast<const uint16_t*>(a.out) + static_cast<size_t>(t < T ? t : T - 1) * a.out_stride + r0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int t = 16 * q + tl;
+        if (t < T) {
+          const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
+          float y0 = 0.f, y1 = 0.f;
+          for (int w = 0; w < ksplit; ++w) {
+            y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
+            y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
+          }
+          if constexpr (EPI == EPI_RESID) epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q], true, oldv[q], &st_sq[q], &st_sum[q]);
+          else epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
+        }
+      }
+    }
+  }
+  // the wave-private x regions are dead (every wave passed the barrier above): scratch for the row statistics
+  if constexpr (EPI == EPI_RESID)
+    if (a.xstat_out) resid_stats_publish<TG>(a, st_sq, st_sum, reinterpret_cast<float*>(smem), tid);
+}
+
+template <int EPI, int TG>
+static int launch_slice_one(const GemvArgs& a, int grid, hipStream_t st) {
+  using C = SliceCfg<TG>;
+  const size_t smem = static_cast<size_t>(kGemvWaves) * C::REGION + skinny_part_bytes(TG);
+  static_assert(static_cast<size_t>(kGemvWaves) * C::REGION + sizeof(float) * kGemvWaves * TG * 256 <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_slice_kernel<EPI, TG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_slice_kernel<EPI, TG>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// shapes the wave-private kernel takes: whole sub-slices per wave, equal K slices
+static bool slice_covers(const GemvArgs& a, const GemvGeom& q, int TG) {
+  const int W = TG <= 3 ? 64 : 32;
+  return TG >= 1 && TG <= 4 && q.kw % W == 0 && q.kw * q.ksplit == a.K && q.n_tiles <= kGemvWaves / q.ksplit;
+}
+
+template <int EPI>
+static int launch_slice(const GemvArgs& a, int grid, hipStream_t st) {
+  switch ((a.T + 15) / 16) {
+    case 1: return launch_slice_one<EPI, 1>(a, grid, st);
+    case 2: return launch_slice_one<EPI, 2>(a, grid, st);
+    case 3: return launch_slice_one<EPI, 3>(a, grid, st);
+    default: return launch_slice_one<EPI, 4>(a, grid, st);
   }
 }
 
 template <int EPI>
 static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
   const int TG = (a.T + 15) / 16;
-  const size_t smem = skinny_part_bytes(TG);   // <= 64 KiB
+  const size_t smem = skinny_part_bytes(TG) + sizeof(float) * kGemvWaves * TG * 32;   // partials + row-statistics scratch, <= 72 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_direct_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
   switch (TG) {
     case 1: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 1>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
     case 2: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 2>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
@@ -586,6 +810,22 @@ static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, 
   return a.w8 ? launch_skinny_w<EPI, true>(a, sg, grid, smem, st) : launch_skinny_w<EPI, false>(a, sg, grid, smem, st);
 }
 
+// mirrors the dispatch of launch_gemm_skinny for an EPI_RESID launch: direct, slice and pipe kernels publish the row
+// statistics (xstat_out), the chunked fallback below does not
+bool gemm_resid_publishes_stats(const GemvArgs& a) {
+  if (a.T <= kGemvMaxT || a.T > 64 || a.x_row) return false;
+  const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
+  const int TG = (a.T + 15) / 16;
+  const bool single_round = q.n_tiles <= kGemvWaves / q.ksplit;
+  if (TG == 1 && !a.w8 && a.prologue == PRO_NONE && single_round && !getenv("SPECDEC_NO_DIRECT")) return true;
+  static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
+  if (a.T >= slice_min_t && a.T <= 48 && !a.w8 && a.prologue == PRO_NONE) {
+    GemvArgs b = a;
+    if (slice_covers(b, q, TG)) return true;
+  }
+  return !getenv("SPECDEC_NO_PIPE") && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0);
+}
+
 bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8) {
   if (T < 1 || T > kSkinnyMaxT || n_pairs < 1) return false;
   const GemvGeom q = gemv_geometry(n_pairs, K);
@@ -618,6 +858,17 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   // touch 16 rows x 64 bytes per instruction)
   if (TG == 1 && !a.w8 && a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
     if (epi == EPI_RESID) return launch_direct<EPI_RESID>(a, q.grid, st);
+  }
+  // ... and from 17 tokens the wave-private staging (SPECDEC_SLICE_MIN_T moves the hand-over for experiments)
+  {
+    static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
+    if (a.T >= slice_min_t && a.T <= 48 && !a.w8 && a.prologue == PRO_NONE && epi == EPI_RESID && slice_covers(a, q, (a.T + 15) / 16))
+      return launch_slice<EPI_RESID>(a, q.grid, st);
+  }
+  // the statically scheduled chunk pipeline (gemm_pipe.hip) for everything else up to 64 tokens
+  {
+    static const bool no_pipe = getenv("SPECDEC_NO_PIPE") != nullptr;
+    if (!no_pipe && a.T <= 64 && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return launch_gemm_pipe(a, q, epi, st);
   }
   const size_t smem = skinny_smem(a.T, TG, sg.kc);
   switch (epi) {

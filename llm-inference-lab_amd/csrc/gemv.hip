@@ -306,12 +306,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         float s1 = 0.f, s2 = 0.f;
         if (wave_has_chunk) {
           const bool need_mean = a.prologue == PRO_LAYERNORM;   // kernel-uniform: RMSNorm only needs the squares
+          f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(xr[t][j] << 16), hi = __uint_as_float(xr[t][j] & 0xffff0000u);
-            if (need_mean) s1 += lo + hi;
-            s2 += lo * lo + hi * hi;
+            const f32x2_t v = bf16x2_unpack(xr[t][j]);
+            if (need_mean) a1 += v;
+            a2 += v * v;
           }
+          s1 = a1.x + a1.y;
+          s2 = a2.x + a2.y;
           if (!has_chunk) { s1 = 0.f; s2 = 0.f; }  // clamped (duplicate) loads do not count
           if (need_mean) s1 = wave_reduce_sum(s1);
           s2 = wave_reduce_sum(s2);
@@ -335,23 +338,13 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
           // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(bf16)
           const float rs = rsqrtf(sq * invK + a.norm_eps);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float x0 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xr[t][j] << 16) * rs));
-            const float x1 = bf16_bits_to_float(float_to_bf16_bits(__uint_as_float(xr[t][j] & 0xffff0000u) * rs));
-            o[j] = static_cast<uint32_t>(float_to_bf16_bits(x0 * __uint_as_float(nw4[j] << 16))) |
-                   (static_cast<uint32_t>(float_to_bf16_bits(x1 * __uint_as_float(nw4[j] & 0xffff0000u))) << 16);
-          }
+          for (int j = 0; j < 4; ++j) o[j] = rmsnorm_pair(xr[t][j], rs, nw4[j]);   // packed math (common.h): same bits, half the VALU work
         } else {
           // GPT-2 LayerNorm in fp32, rounded once
           const float mean = sum * invK;
           const float rs = rsqrtf(fmaxf(sq * invK - mean * mean, 0.f) + a.norm_eps);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float y0 = (__uint_as_float(xr[t][j] << 16) - mean) * rs * __uint_as_float(nw4[j] << 16) + __uint_as_float(nb4[j] << 16);
-            const float y1 = (__uint_as_float(xr[t][j] & 0xffff0000u) - mean) * rs * __uint_as_float(nw4[j] & 0xffff0000u) +
-                             __uint_as_float(nb4[j] & 0xffff0000u);
-            o[j] = static_cast<uint32_t>(float_to_bf16_bits(y0)) | (static_cast<uint32_t>(float_to_bf16_bits(y1)) << 16);
-          }
+          for (int j = 0; j < 4; ++j) o[j] = layernorm_pair(xr[t][j], mean, rs, nw4[j], nb4[j]);
         }
         if (has_chunk) *reinterpret_cast<u32x4*>(xs + static_cast<size_t>(t) * KP + tid * 8) = o;
       }

@@ -70,7 +70,7 @@ __device__ __forceinline__ void pair_rows(const GemvArgs& a, int p, int& r0, int
 template <int EPI, bool COH = false>
 __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r1, int t, float y0,
                                          float y1, float& best_v, int& best_i, bool have_old = false,
-                                         uint32_t old_pre = 0) {
+                                         uint32_t old_pre = 0, float* st_sq = nullptr, float* st_sum = nullptr) {
   const int b = static_cast<int>((static_cast<unsigned>(t) * a.m_magic) >> 16), m = t - b * a.M;   // t / M (gemv_derive)
   if constexpr (EPI == EPI_QKV_ROPE) {
     if (a.bias) {
@@ -122,6 +122,11 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
     const uint32_t nv = static_cast<uint32_t>(float_to_bf16_bits(n0)) | (static_cast<uint32_t>(float_to_bf16_bits(n1)) << 16);
     if constexpr (COH) __hip_atomic_store(px, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *px = nv;
+    if (st_sq) {   // statistics of the row AS STORED (bf16-rounded), for the launch that normalises it (GemvArgs::xstat_out)
+      const float r0f = __uint_as_float(nv << 16), r1f = __uint_as_float(nv & 0xffff0000u);
+      *st_sq += r0f * r0f + r1f * r1f;
+      *st_sum += r0f + r1f;
+    }
   } else if constexpr (EPI == EPI_SWIGLU) {
     const float g = y0, u = y1;
     const float act = g / (1.0f + __expf(-g)) * u;
@@ -149,6 +154,40 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
         lo[r0] = u0;
         if (r1 < a.N) lo[r1] = u1;
       }
+    }
+  }
+}
+
+// EPI_RESID launches at > 9 tokens: thread `tid` holds, for tokens 16 q + (tid & 15), the (sum of squares, sum) of the new
+// row values of the pairs it finished. Folded over the workgroup in a fixed order (lanes that share a token: xor 16, 32;
+// then the 16 waves through `scratch`, >= 16 * TG * 32 floats of LDS nobody else is using) and written as this
+// workgroup's partial of every token. Called by all threads of the workgroup.
+template <int TG>
+__device__ __forceinline__ void resid_stats_publish(const GemvArgs& a, const float (&sq)[TG], const float (&sm)[TG], float* scratch, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    float v2 = sq[q], v1 = sm[q];
+    v2 += __shfl_xor(v2, 16, 64);
+    v2 += __shfl_xor(v2, 32, 64);
+    v1 += __shfl_xor(v1, 16, 64);
+    v1 += __shfl_xor(v1, 32, 64);
+    if (lane < 16) {
+      scratch[((wave * TG + q) * 16 + lane) * 2 + 0] = v2;
+      scratch[((wave * TG + q) * 16 + lane) * 2 + 1] = v1;
+    }
+  }
+  __syncthreads();
+  if (tid < 16 * TG) {
+    const int q = tid >> 4, tl = tid & 15, t = 16 * q + tl;
+    if (t < a.T) {
+      float v2 = 0.f, v1 = 0.f;
+      for (int w = 0; w < kGemvWaves; ++w) {
+        v2 += scratch[((w * TG + q) * 16 + tl) * 2 + 0];
+        v1 += scratch[((w * TG + q) * 16 + tl) * 2 + 1];
+      }
+      a.xstat_out[static_cast<size_t>(t) * kStatStride + blockIdx.x] = v2;
+      a.xstat_out[kStatPlane + static_cast<size_t>(t) * kStatStride + blockIdx.x] = v1;
     }
   }
 }

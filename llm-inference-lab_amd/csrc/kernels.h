@@ -63,7 +63,18 @@ struct GemvArgs {
   // ARGMAX epilogue: per-workgroup partials [T][grid]
   float* part_val;
   int* part_idx;
+  // Row statistics handed from the kernel that WRITES the residual stream to the kernel that normalises it (> 9 tokens):
+  // an EPI_RESID launch with xstat_out != null leaves, per token t and workgroup c, the sum of squares and the sum of the
+  // new row values over the columns c owns: xstat_out[t * kStatStride + c] and xstat_out[kStatPlane + t * kStatStride + c].
+  // A norm-fused launch with xstat_in != null adds the xstat_n partials of a token in a fixed order instead of reading
+  // the whole row again (every one of its 256 workgroups would: 63 MB of L2 -> CU traffic at 40 tokens, 6-9 us).
+  float* xstat_out;
+  const float* xstat_in;
+  int xstat_n;
 };
+constexpr int kStatStride = 256;                    // partials per token (>= workgroups of the producing launch)
+constexpr int kStatPlane = kSkinnyMaxT * kStatStride;   // floats per plane (plane 0: sum of squares, plane 1: sum)
+bool gemm_resid_publishes_stats(const GemvArgs& a);  // true when launch_gemv(a, EPI_RESID) takes a kernel that honours xstat_out
 
 
 // fields of GemvArgs every launcher derives from the caller's (idempotent)
@@ -94,6 +105,10 @@ int gemv_max_tokens(int K);                                          // tokens g
 int launch_gemv(const GemvArgs& a, int epi, hipStream_t st);          // T <= 9: gemv.hip, else gemm_skinny.hip
 int launch_gemm_skinny(const GemvArgs& a, int epi, hipStream_t st);   // T <= 64
 bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8 = false);                  // shape handled by gemm_skinny.hip
+// gemm_pipe.hip: the statically scheduled chunk pipeline for <= 64 tokens (tried first by launch_gemm_skinny, which has
+// set the work split fields of `a`)
+bool gemm_pipe_covers(int T, int n_pairs, int K, bool w8 = false);
+int launch_gemm_pipe(const GemvArgs& a, const GemvGeom& q, int epi, hipStream_t st);
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------
 struct AttnArgs {

@@ -295,8 +295,10 @@ class OraclePipeline:
         return draft
 
     def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int,
-                       max_steps: Optional[int] = None, sampling: Optional[Dict] = None) -> List[Dict]:
-        """`max_steps` (not in the reference) bounds a timing sample to a number of steps.
+                       max_steps: Optional[int] = None, sampling: Optional[Dict] = None,
+                       step_log: Optional[List] = None) -> List[Dict]:
+        """`max_steps` (not in the reference) bounds a timing sample to a number of steps; `step_log`, when given,
+        receives (wall clock, tokens generated so far over all rows) after every step (bench.py times segments with it).
         `sampling` = {temperature, top_k, top_p, seed} turns on do_sample=True: drafting and
         verification stay greedy (pipeline.py:2400, :2645); only the token after the accepted
         prefix is sampled (oracle/sampling_ref.py), one Philox draw per row per step, stream = row."""
@@ -331,6 +333,8 @@ class OraclePipeline:
                     r.draws += 1
                 self.trace.append({"step": step, "row": i, "a": a, "draft": draft, "t": t[: a + 1],
                                    "appended": appended, "seq_len": before})
+            if step_log is not None:
+                step_log.append((time.time(), sum(len(r.generated) for r in rows)))
         dt = time.time() - t0
         return [self._result(r, dt, len(rows), i) for i, r in enumerate(rows)]
 

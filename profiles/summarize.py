@@ -1,5 +1,5 @@
 """Summarise rocprofv3 output of a bench.py run (kernel-trace stats + PMC passes) into a
-small table. Usage: python profiles/summarize.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> [traffic.json] > profiles/<name>.md
+small table. Usage: python profiles/summarize.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> [traffic.json [libspecdec_hip.so [workload]]] > profiles/<name>.md
 FETCH_SIZE is in KiB and, on gfx950, counts exactly half of a 16-B/lane coalesced stream
 (MI355X_MICROARCH.md §HBM): the corrected figure doubles it. WRITE_SIZE is exact."""
 
@@ -51,6 +51,11 @@ def main():
                 rd, wr = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
                 tr[key[0].split("(")[0]] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_x2_corrected": rd, "write_bytes": wr,
                                             "launches_counted": len(f)}
+        if len(sys.argv) > 5:   # stamp: content hash of the library the counters were taken with + the workload
+            import hashlib
+
+            tr["_meta"] = {"lib_sha256": hashlib.sha256(open(sys.argv[5], "rb").read()).hexdigest(),
+                           "workload": sys.argv[6] if len(sys.argv) > 6 else None}
         with open(sys.argv[4], "w") as fo:
             json.dump(tr, fo, indent=1)
     print("| kernel | LDS B | launches | avg us | total ms | % | FETCH KiB/launch (raw) | HBM read MB/launch (x2 corrected) | WRITE KiB/launch |")

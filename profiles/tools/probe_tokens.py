@@ -13,13 +13,13 @@ preset = {"3b": W.LLAMA_3_2_3B, "1b": W.LLAMA_3_2_1B, "8b": W.LLAMA_3_8B}[sys.ar
 mw = W.synthetic_llama(preset, seed=0, device="cuda")
 hm = HipModel(mw, batch=1, l_max=64)
 st = torch.cuda.Stream()
-names = {1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head"}
-print("tokens | " + " | ".join(f"{names[w]:>16s}" for w in (1, 2, 3, 4)) + "   (us, TB/s)")
-for T in (1, 5, 9, 10, 16, 17, 24, 32, 40, 48, 64, 80, 96, 128):
+names = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head"}
+print("tokens | " + " | ".join(f"{names[w]:>16s}" for w in (0, 1, 2, 3, 4)) + "   (us, TB/s)")
+for T in [int(t) for t in os.environ.get("PROBE_TOKENS", "1,5,9,10,16,17,24,32,40,48,64,80,96,128").split(",")]:
     if T > hm.pass_tokens:
         break
     row = []
-    for which in (1, 2, 3, 4):
+    for which in (0, 1, 2, 3, 4):
         us, nb = hm.probe_gemv(which, T=T, iters=120 if which != 4 else 40, stream=st)
         row.append(f"{us:7.1f} {nb / us / 1e6:6.2f}")
     print(f"{T:6d} | " + " | ".join(f"{r:>16s}" for r in row), flush=True)
