@@ -141,9 +141,13 @@ class SpeculativePipeline:
             raise ValueError(f"draft/base vocabularies differ: {self.draft_lm.vocab_size} vs {self.base_lm.vocab_size}")
         self.speculative_enabled = True
         self.policy = create_policy(policy, **(policy_params or {}))
-        if policy != "longest_prefix":
-            raise NotImplementedError("only the longest_prefix policy runs inside the device step; the other "
-                                      "policies are available through policies.create_policy for host use")
+        # longest_prefix (exact match) is the policy inside the captured device step. The logit-threshold policies
+        # (typical, topk_agree, conf_threshold) take the reference's own route (_decode_host_policy): they compare the draft with
+        # what the base model generates by itself from the same prefix, which a parallel pass over the DRAFT tokens does
+        # not give once a non-argmax draft token is accepted.
+        self.policy_name = policy
+        if policy != "longest_prefix" and (mode != "vanilla" or medusa_heads is not None):
+            raise NotImplementedError(f"policy={policy!r} drafts with the draft model (draft_mode='vanilla')")
         self.controller = create_controller(controller, **(controller_params or {}))
         from src.scheduler import create_speculative_scheduler
 
@@ -316,6 +320,61 @@ class SpeculativePipeline:
         st["k"] = sess.k
         return sess.rows, st
 
+    def _decode_host_policy(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int):
+        """The reference's verification for the logit-threshold policies (speculative_scheduler.py:294-368, policies.py:213-396;
+        pipeline.py:1019-1100 and :2397-3030): per row and step, K greedy draft tokens with their logits, the base model's
+        OWN K greedy tokens with their logits from the same prefix (K one-token HIP forwards each, over the rows' cached
+        prefixes), the policy on the device logits, then the same host rules as the device step. A full acceptance takes
+        the extra base forward the reference takes (:3199-3206)."""
+        t_start = time.time()
+        rows = [_Row(list(p)) for p in prompts]
+        for r in rows:
+            if not r.seq:
+                raise ValueError("empty prompt")
+        eos = self.base_lm.get_tokenizer_info().get("eos_token_id")
+        n = len(rows)
+        for lm in (self.base_lm, self.draft_lm):
+            lm.clear_kv_cache()
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
+        step = 0
+        while any(r.active for r in rows):
+            step += 1
+            ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
+                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+            k = int(self.controller.get_k(step, ctx))
+            if k <= 0:
+                break
+            t0 = time.time()
+            for b, r in enumerate(rows):
+                if not r.active:
+                    continue
+                ids = torch.tensor([r.seq], dtype=torch.long)
+                d_ids, d_logits = self.draft_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
+                b_ids, b_logits = self.base_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
+                a, _info = self.policy.accept_tokens(d_ids, b_ids, d_logits, b_logits)
+                d, t = d_ids[0].tolist(), b_ids[0].tolist()
+                if a == k and emit_mode == HipSpecDec.EMIT_BONUS:
+                    more, _ = self.base_lm.generate_tokens(torch.tensor([r.seq + t], dtype=torch.long), 1, do_sample=False, row=b, rows=n)
+                    t.append(int(more[0, 0]))
+                else:
+                    t.append(-1)
+                acc0 = r.accepted
+                if emit_mode == HipSpecDec.EMIT_BONUS:
+                    self._rules_batch(r, k, a, t, max_tokens, eos)
+                else:
+                    self._rules_single(r, k, a, d, t, max_tokens, eos)
+                r.steps += 1
+                stats["proposed"] += k
+                stats["accepted"] += r.accepted - acc0
+                if r.active and r.steps >= step_limit:
+                    r.active = False
+            stats["device_ms"] += (time.time() - t0) * 1e3
+        torch.cuda.synchronize()
+        stats["steps"] = max((r.steps for r in rows), default=0)
+        stats["total_ms"] = (time.time() - t_start) * 1e3
+        stats["k"] = int(getattr(self.controller, "k", 0) or 0)
+        return rows, stats
+
     # ------------------------------------------------------------------ public API
     def _sampling_config(self, do_sample: bool, temperature: float, kwargs: Dict[str, Any]) -> Optional[Dict[str, Any]]:
         """Sampler parameters of a do_sample=True run (kwargs over config, pipeline.py:3148-3153)."""
@@ -347,8 +406,11 @@ class SpeculativePipeline:
         ids = self._encode(prompt)
         # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
         # drafts with the draft model
-        rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
-                                self_draft=self.config.get("draft_mode") in ("medusa", "eagle"))
+        if self.policy_name != "longest_prefix":
+            rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens)
+        else:
+            rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
+                                    self_draft=self.config.get("draft_mode") in ("medusa", "eagle"))
         r = rows[0]
         total_ms = (time.time() - t_begin) * 1e3
         self.metrics = {"total_proposed": r.proposed, "total_accepted": r.accepted, "total_steps": st["steps"],
@@ -381,7 +443,12 @@ class SpeculativePipeline:
         if self.draft_lm is None and not heads:
             raise ValueError("generate_batch drafts with the draft model (the reference ignores draft_mode there): pass draft_lm / draft_model")
         ids = [self._encode(p) for p in prompts]
-        rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling, self_draft=heads)
+        if self.policy_name != "longest_prefix":
+            if sampling is not None:
+                raise NotImplementedError(f"policy={self.policy_name!r} with do_sample=True is not on the HIP path")
+            rows, st = self._decode_host_policy(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens)
+        else:
+            rows, st = self._decode(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens, sampling=sampling, self_draft=heads)
         total_ms = st["total_ms"]
         tot_prop = sum(r.proposed for r in rows)
         tot_acc = sum(r.accepted for r in rows)

@@ -86,11 +86,17 @@ class HipLM(LanguageModel):
                         do_sample: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """k tokens + their logits [B, k, V] (fp32), one forward per token
         (hf_wrappers.py:272-627 semantics: argmax of the last position; with do_sample the
-        token is drawn from softmax(logits / T))."""
+        token is drawn from softmax(logits / T)). `row=b, rows=n` (one sequence): use cache row b of an n-row engine, so
+        that several sequences of different lengths each keep their own cached prefix."""
         if input_ids.dim() == 1:
             input_ids = input_ids.unsqueeze(0)
         ids = validate_and_clamp_tokens(input_ids.long(), self.vocab_size, "generate_tokens")
         B, L = ids.shape
+        row0 = int(kwargs.get("row", 0))
+        if row0 or kwargs.get("rows"):
+            if B != 1:
+                raise ValueError("generate_tokens(row=...) takes one sequence")
+            return self._generate_row(ids, max_new_tokens, row0, int(kwargs.get("rows") or row0 + 1))
         m = self._engine(B, L + max_new_tokens + 1)
         host = ids.cpu().tolist()
         dev = self._device
@@ -125,6 +131,37 @@ class HipLM(LanguageModel):
         if not out_ids:
             return (torch.empty((B, 0), dtype=torch.long, device=dev),
                     torch.empty((B, 0, self.vocab_size), dtype=torch.float32, device=dev))
+        return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
+
+    def _generate_row(self, ids: torch.Tensor, k: int, b: int, rows: int):
+        """Greedy generate_tokens of ONE sequence in cache row b (prefix reuse per row)."""
+        L = ids.shape[1]
+        m = self._engine(rows, L + k + 1)
+        dev = self._device
+        host = ids[0].cpu().tolist()
+        have = self._cached[b]
+        common = 0
+        for x, y in zip(have, host[:-1]):
+            if x != y:
+                break
+            common += 1
+        todo = host[common : L - 1]
+        if todo:
+            m.forward(torch.tensor([todo], dtype=torch.int32, device=dev), torch.tensor([common], dtype=torch.int32, device=dev), 0,
+                      skip_head=True, row0=b)
+        self._cached[b] = list(host[: L - 1])
+        cur = ids[:, -1:].to(dev, torch.int32).contiguous()
+        pos = torch.full((1,), L - 1, dtype=torch.int32, device=dev)
+        out_ids, out_logits = [], []
+        for _ in range(k):
+            nxt, logits = m.forward(cur, pos, 0, want_logits=True, logits_dtype=torch.float32, row0=b)
+            self._cached[b].append(int(cur[0, 0]))
+            out_ids.append(nxt.long())
+            out_logits.append(logits[:, 0, :])
+            cur = nxt.to(torch.int32).contiguous()
+            pos = pos + 1
+        if not out_ids:
+            return (torch.empty((1, 0), dtype=torch.long, device=dev), torch.empty((1, 0, self.vocab_size), dtype=torch.float32, device=dev))
         return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
 
     def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor):

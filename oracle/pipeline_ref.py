@@ -172,7 +172,8 @@ class OraclePipeline:
 
     def __init__(self, base: OracleLM, draft: Optional[OracleLM], k: int = 4, eos_token_id: Optional[int] = None,
                  reprefill: bool = False, draft_mode: str = "vanilla", medusa_heads=None, eagle_alpha: float = 0.7,
-                 medusa_num_heads: int = 2, medusa_temperature: float = 0.7):
+                 medusa_num_heads: int = 2, medusa_temperature: float = 0.7, policy: str = "longest_prefix",
+                 policy_params: Optional[Dict] = None):
         """draft_mode "medusa_tied": the reference's MedusaDraftor (src/specdec/modes/medusa.py:71-186) with
         head_init tie/copy under greedy decoding — every head is the base lm_head and head 0 is evaluated on the
         same last hidden state for each of the K proposals, so the draft is K copies of the base model's own
@@ -191,6 +192,11 @@ class OraclePipeline:
         self.medusa_num_heads, self.medusa_temperature = int(medusa_num_heads), float(medusa_temperature)
         self._eagle_state: Dict[int, torch.Tensor] = {}
         self._next_draft: Dict[int, List[int]] = {}
+        # acceptance policy (policies.py:76-425). "longest_prefix" compares ids (exact match: one cached K+1 pass gives the
+        # same answer as the reference's autoregressive base pass); the logit-threshold policies need what the reference
+        # computes — the base model's OWN K greedy tokens and their logits from the same prefix
+        # (speculative_scheduler.py:294-368), and the draft's logits
+        self.policy, self.policy_params = policy, dict(policy_params or {})
         self.eos = eos_token_id
         self.reprefill = reprefill
         self.vocab = base.cfg.vocab
@@ -201,6 +207,8 @@ class OraclePipeline:
         tokens t_0..t_K conditioned on seq + draft[:i]."""
         k = self.k
         ids = torch.tensor([seq], dtype=torch.int64)
+        if self.policy != "longest_prefix":
+            return self._propose_and_verify_policy(ids, seq, k)
         if self.draft_mode == "medusa_heads":
             draft = self._next_draft.get(row, [0] * k)
             lg, _ = self.base.forward(torch.tensor([seq + draft], dtype=torch.int64))
@@ -241,6 +249,32 @@ class OraclePipeline:
         self.last_logits = lg[0, len(seq) - 1 :]     # [K+1][V]: what the sampled bonus token is drawn from
         t = self.last_logits.argmax(-1).tolist()
         a = longest_prefix(draft, t)
+        return draft, t, a
+
+    def _propose_and_verify_policy(self, ids: torch.Tensor, seq: List[int], k: int):
+        """pipeline.py:1019-1100 / :2397-3030 with a logit-threshold policy: K greedy draft tokens with their logits, the
+        base model's own K greedy tokens with their logits from the SAME prefix, the policy on (draft ids, draft
+        logits, base logits); t = base tokens (+ the extra forward's token after a full acceptance, :3199-3206)."""
+        from .hostlogic_ref import conf_threshold_accept, topk_agree_accept, typical_accept
+
+        d_ids, d_logits = self.draft.generate_tokens(ids, k, reprefill=self.reprefill)
+        b_ids, b_logits = self.base.generate_tokens(ids, k, reprefill=self.reprefill)
+        draft, base = d_ids[0].tolist(), b_ids[0].tolist()
+        pp = self.policy_params
+        if self.policy == "conf_threshold":
+            a = conf_threshold_accept(draft, d_logits[0], float(pp.get("tau", 0.5)))
+        elif self.policy == "topk_agree":
+            a = topk_agree_accept(draft, b_logits[0], int(pp.get("k", 5)))
+        elif self.policy == "typical":
+            a = typical_accept(draft, b_logits[0], float(pp.get("p", 0.9)))
+        else:
+            raise ValueError(f"unknown policy {self.policy!r}")
+        t = list(base)
+        if a == k:
+            lg, _ = self.base.forward(torch.tensor([seq + base], dtype=torch.int64))
+            t.append(int(lg[0, -1].argmax()))
+        else:
+            t.append(-1)
         return draft, t, a
 
     def _medusa_random_draft(self, ids: torch.Tensor, k: int) -> List[int]:

@@ -145,6 +145,28 @@ def g8_pairs(dtype=torch.float32):
     return out
 
 
+def policy_pair(dtype=torch.float32):
+    """A G8-shaped pair whose output tables are scaled by 0.12: the greedy token still wins by ~5 logits (argmax is
+    robust to bf16 / summation order) but its softmax probability is ~0.9 and the runners-up matter, so the
+    logit-threshold policies (typical, topk_agree, conf_threshold) accept and reject differently from exact match."""
+    from specdec_hip import weights as W
+
+    rs = {"factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+          "original_max_position_embeddings": 64, "rope_type": "llama3"}
+    kw = dict(arch=W.ARCH_LLAMA, d_model=64, n_heads=2, n_kv_heads=1, head_dim=32, d_ff=128, vocab=160, max_pos=256,
+              rope_theta=500000.0, tie_embeddings=False, eos_token_id=2, rope_scaling=rs)
+    tgt = W.synthetic_llama(W.ModelConfig(n_layers=2, name="pol-target", **kw), seed=31, dtype=dtype, layer_gain=0.05,
+                            successor_mult=37, successor_add=5)
+    tgt.lm_head = (tgt.lm_head.float() * 0.12).to(dtype)
+    drf = W.synthetic_llama(W.ModelConfig(n_layers=1, name="pol-draft", **kw), seed=32, dtype=dtype, layer_gain=0.05,
+                            successor_mult=37, successor_add=5, embed_from=tgt, flip_fraction=0.3)
+    return drf, tgt
+
+
+POLICY_RUNS = [("typical", {"p": 0.9}), ("typical", {"p": 0.5}), ("topk_agree", {"k": 20}), ("topk_agree", {"k": 2}),
+               ("conf_threshold", {"tau": 0.9}), ("conf_threshold", {"tau": 0.6})]
+
+
 def weights_checksum(mw) -> float:
     return float(sum(checksum(t) for name, t in mw.tensors() if not name.startswith("rope_")))
 

@@ -344,6 +344,45 @@ def gen_medusa():
         json.dump(out, f, indent=1, default=str)
 
 
+def gen_pipeline_policies():
+    """Traces of the REFERENCE pipeline with the logit-threshold acceptance policies (policies.py:213-396; called at
+    pipeline.py:1092 / :3018) on a pair with soft output distributions (cases.policy_pair): generate_batch and generate,
+    CPU fp32, greedy, KV append off."""
+    import shutil
+    import tempfile
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    SpeculativePipeline = _reference_pipeline_class()
+    d, t = cases.policy_pair(torch.float32)
+    out = {"draft_checksum": cases.weights_checksum(d), "target_checksum": cases.weights_checksum(t), "runs": []}
+    tmp = tempfile.mkdtemp(prefix="g8p_")
+    try:
+        ddir, tdir = os.path.join(tmp, "draft"), os.path.join(tmp, "target")
+        _save_local_hf_llama(d, ddir)
+        _save_local_hf_llama(t, tdir)
+        rng = np.random.default_rng(41)
+        for name, params in cases.POLICY_RUNS:
+            for k in (2, 4):
+                pipe = SpeculativePipeline(base_model=tdir, draft_model=ddir, implementation="hf", device="cpu", policy=name,
+                                           policy_params=params, controller="fixed", controller_params={"k": k}, max_draft=k, seed=1234)
+                prompt_ids = rng.integers(4, t.config.vocab, size=7).tolist()
+                prompt = " ".join(f"t{i:03d}" for i in prompt_ids)
+                rb = pipe.generate_batch([prompt], max_tokens=14, temperature=0.7, do_sample=False)[0]
+                rs = pipe.generate(prompt, max_tokens=14, temperature=0.7, do_sample=False)
+                out["runs"].append({
+                    "policy": name, "params": params, "k": k, "max_tokens": 14, "prompt_ids": prompt_ids,
+                    "batch": {"generated_tokens": [int(x) for x in rb["generated_tokens"]], "proposed": int(rb["proposed"]),
+                              "accepted": int(rb["accepted"]), "steps": int(rb["batch_metrics"]["total_steps"])},
+                    "single": {"generated_tokens": [int(x) for x in rs["generated_tokens"]] if "generated_tokens" in rs else None,
+                               "text": rs.get("text"), "proposed": int(rs["proposed"]), "accepted": int(rs["accepted"]), "steps": int(rs["steps"])}})
+                print(name, params, "k", k, "batch acc", rb["accepted"], "/", rb["proposed"], "| single", rs["accepted"], "/", rs["proposed"], rs.get("text", "")[:50])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "pipeline_policies_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+
+
 def gen_hostlogic():
     """G3-G6: the reference's host-side pieces on seeded inputs (policies, bonus-token
     filtering, controllers, sequence utils, token validation)."""
@@ -440,3 +479,5 @@ if __name__ == "__main__":
         gen_hostlogic()
     if "medusa" in which:
         gen_medusa()
+    if "policies" in which:
+        gen_pipeline_policies()

@@ -358,3 +358,46 @@ def test_persistent_medusa_heads(k, batch, wd):
     ws = oracle.generate(prompts[0], 12)
     assert single["generated_tokens"] == ws["generated_tokens"]
     assert (single["proposed"], single["accepted"], single["steps"]) == (ws["proposed"], ws["accepted"], ws["steps"])
+
+
+def test_logit_threshold_policies_match_oracle_and_reference():
+    """policy = typical / topk_agree / conf_threshold (the reference accepts all four, policies.py:399-425, used at
+    pipeline.py:1092 and :3018): the pipeline takes the reference's own verification for them — the base model's K greedy
+    tokens and logits from the same prefix — with every forward on the HIP engine. Tokens, counters and steps equal the
+    oracle loop on the same bf16 weights, and the reference's own fp32 traces (tests/golden/pipeline_policies_golden.json)."""
+    from src.specdec import HipLM, SpeculativePipeline
+
+    with open(os.path.join(GOLD, "pipeline_policies_golden.json")) as f:
+        g = json.load(f)
+    drf, tgt = cases.policy_pair(torch.bfloat16)
+    base, draft = OracleLM(tgt, "bf16"), OracleLM(drf, "bf16")
+    blm, dlm = HipLM(tgt.to("cuda")), HipLM(drf.to("cuda"))
+    same_as_reference = 0
+    for run in g["runs"]:
+        k, mt, prompt = run["k"], run["max_tokens"], run["prompt_ids"]
+        pipe = SpeculativePipeline(base_lm=blm, draft_lm=dlm, policy=run["policy"], policy_params=run["params"],
+                                   controller="fixed", controller_params={"k": k}, seed=1234)
+        oracle = OraclePipeline(base, draft, k=k, eos_token_id=2, policy=run["policy"], policy_params=run["params"])
+        got = pipe.generate_batch([prompt], max_tokens=mt, do_sample=False)[0]
+        want = oracle.generate_batch([prompt], mt)[0]
+        assert got["generated_tokens"] == want["generated_tokens"], (run["policy"], run["params"], k)
+        assert (got["proposed"], got["accepted"], got["batch_metrics"]["total_steps"]) == (want["proposed"], want["accepted"], want["steps"])
+        gs = pipe.generate(prompt, max_tokens=mt, do_sample=False)
+        ws = oracle.generate(prompt, mt)
+        assert gs["generated_tokens"] == ws["generated_tokens"], (run["policy"], run["params"], k)
+        assert (gs["proposed"], gs["accepted"], gs["steps"]) == (ws["proposed"], ws["accepted"], ws["steps"])
+        assert gs["policy"]["policy"] == run["policy"]
+        ref_b, ref_s = run["batch"], run["single"]
+        same_as_reference += (got["generated_tokens"] == ref_b["generated_tokens"] and got["accepted"] == ref_b["accepted"]
+                              and gs["generated_tokens"] == ref_s["generated_tokens"] and gs["accepted"] == ref_s["accepted"])
+    # a probability threshold can fall between the bf16 and the fp32 value of a borderline token; everything else is the
+    # reference's trace exactly
+    assert same_as_reference >= len(g["runs"]) - 2, same_as_reference
+    # two rows of different lengths keep their own cached prefixes
+    pipe = SpeculativePipeline(base_lm=blm, draft_lm=dlm, policy="topk_agree", policy_params={"k": 20}, controller="fixed",
+                               controller_params={"k": 4}, seed=1234)
+    oracle = OraclePipeline(base, draft, k=4, eos_token_id=2, policy="topk_agree", policy_params={"k": 20})
+    prompts = [g["runs"][0]["prompt_ids"], g["runs"][1]["prompt_ids"][:4]]
+    got, want = pipe.generate_batch(prompts, max_tokens=10, do_sample=False), oracle.generate_batch(prompts, 10)
+    for a, b in zip(got, want):
+        assert a["generated_tokens"] == b["generated_tokens"] and (a["proposed"], a["accepted"]) == (b["proposed"], b["accepted"])
