@@ -257,6 +257,13 @@ int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stride,
                      int32_t* ids_out, int ids_stride,
                      void* logits_out, int logits_dtype, int skip_head, void* stream);
 
+/* The residual-stream rows (bf16 [n][d_model], BEFORE the final norm) that the last pass of the last sd_model_forward
+ * left in the workspace: token (b, m) of that pass is row b*M + m. Rows [row0, row0+n) are copied to `out` (device
+ * memory), asynchronously on `stream`. This is `outputs.hidden_states` of the reference's draft modes one norm earlier:
+ * _run_medusa_hf / _run_eagle_hf read hidden_states[-1][:, -1] (src/specdec/core/pipeline.py:674-686, 788-800), i.e.
+ * final_norm(row). */
+int sd_model_hidden_rows(sd_model* m, int row0, int n, void* out, void* stream);
+
 /* Measurement hook for bench.py's roofline leg: launches ONE of the forward's weight-
  * streaming GEMVs (which: 1 = attention out-proj, 2 = norm+gate/up+SwiGLU, 3 = down-proj,
  * 4 = final norm+lm_head+argmax) `iters` times, round-robin over the layers so the weights

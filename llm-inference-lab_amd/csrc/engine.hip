@@ -448,6 +448,16 @@ extern "C" int sd_model_forward(sd_model* m, const int32_t* tokens, int tok_stri
                        logits_dtype, skip_head, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int sd_model_hidden_rows(sd_model* m, int row0, int n, void* out, void* stream) {
+  clear_error();
+  SD_REQUIRE(m && m->x && out, "hidden_rows: NULL argument / model not bound");
+  SD_REQUIRE(row0 >= 0 && n >= 1 && row0 + n <= kSkinnyMaxT, "hidden_rows: rows [%d,%d) outside the %d rows of a pass", row0, row0 + n, kSkinnyMaxT);
+  const size_t d = static_cast<size_t>(m->cfg.d_model);
+  SD_HIP_CHECK(hipMemcpyAsync(out, m->x + static_cast<size_t>(row0) * d, static_cast<size_t>(n) * d * 2, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 // Measurement hook (bench.py "roofline" leg): one GEMV of the forward, launched `iters`
 // times round-robin over the layers (so the weights come from HBM, not from the 256 MiB
 // Infinity Cache) between two HIP events on `stream`.

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sd_model_destroy": (_c_int, [_c_void_p]),
     "sd_quantize_fp8_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "sd_model_pass_tokens": (_c_int, [_c_void_p]),
+    "sd_model_hidden_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "sd_model_workspace_bytes": (_c_size, [_c_void_p]),
     "sd_model_kv_bytes": (_c_size, [_c_void_p, _c_int, _c_int]),
     "sd_model_bind": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_size]),

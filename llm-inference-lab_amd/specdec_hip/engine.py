@@ -143,6 +143,14 @@ class HipModel:
         _abi.check(rc, "sd_model_forward")
         return ids, logits
 
+    def hidden_rows(self, n: int, row0: int = 0, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        """bf16 [n][d_model]: the residual-stream rows (before the final norm) of the last forward pass (sd_model_hidden_rows)."""
+        out = torch.empty((n, self.cfg.d_model), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_model_hidden_rows(self.handle, int(row0), int(n), out.data_ptr(), _stream(stream, self.device)),
+                       "sd_model_hidden_rows")
+        return out
+
     @property
     def pass_tokens(self) -> int:
         """Tokens per forward pass (64 with the multi-token kernel, else 9)."""

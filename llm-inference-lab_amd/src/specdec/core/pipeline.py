@@ -109,8 +109,11 @@ class SpeculativePipeline:
             # lm_head, head 0 evaluated on the same last hidden state for all K proposals -> K copies of the
             # target's own next token. The pipeline's HF path re-creates RANDOM heads on every call
             # (pipeline.py:689-705), which has no reproducible restatement; `head_init: random` is refused.
-            if self.config.get("medusa", {}).get("head_init", "tie") not in ("tie", "copy"):
-                raise NotImplementedError("draft_mode='medusa' needs medusa.head_init 'tie' or 'copy' (random heads are not restated)")
+            # `head_init: random` is what the reference PIPELINE runs for every Medusa configuration (_run_medusa_hf,
+            # pipeline.py:655-763: fresh nn.Linear heads with normal_(0, 0.02) weights and multinomial draws from the global
+            # torch generator on every step): _draft_medusa_random below, generate() only.
+            if self.config.get("medusa", {}).get("head_init", "tie") not in ("tie", "copy", "random"):
+                raise ValueError("medusa.head_init must be 'tie', 'copy' or 'random'")
         elif mode == "eagle":
             # EAGLE-lite as the reference's HF path defines it (_run_eagle_hf, pipeline.py:765-889): draft tokens are the
             # argmax of the lm_head over hidden states extrapolated from the target's last two states, min(k, max_draft)
@@ -320,7 +323,42 @@ class SpeculativePipeline:
         st["k"] = sess.k
         return sess.rows, st
 
-    def _decode_host_policy(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int):
+    def _medusa_random(self) -> bool:
+        return (self.config.get("draft_mode") == "medusa" and self.medusa_heads is None
+                and self.config.get("medusa", {}).get("head_init", "tie") == "random")
+
+    def _draft_medusa_random(self, seq: List[int], k: int, temperature: float, row: int, rows: int):
+        """_run_medusa_hf (pipeline.py:655-763) on the HIP engine: the target's last hidden state (after the final norm) of
+        the last token; `num_heads` FRESH heads per call — torch.nn.Linear's default init, then normal_(0, 0.02), both from
+        the global torch generator on the host, exactly as the reference creates them; every head still in range draws one
+        token per proposal with torch.multinomial from softmax(logits / T) (global generator, host); the proposal of a step
+        is head 0's draw. The hidden state does not move between proposals, so every head's logits are computed once
+        (a [num_heads x V x d] product on the device, bf16 as the engine holds weights). Returns (ids [1,k], logits [1,k,V])."""
+        h = self.base_lm.last_hidden_state(torch.tensor([seq], dtype=torch.long), row=row, rows=rows)   # [1,1,d] fp32, bf16 values
+        num_heads = int(self.config.get("medusa", {}).get("num_heads", 2))
+        d, V = h.shape[-1], self.base_lm.vocab_size
+        heads = []
+        for _ in range(num_heads):
+            head = torch.nn.Linear(d, V, bias=False)
+            torch.nn.init.normal_(head.weight, 0, 0.02)
+            heads.append(head.weight.detach().to(torch.bfloat16))
+        hw = torch.stack(heads).to("cuda").float()                                    # [H,V,d], bf16 values
+        logits = torch.matmul(hw, h.view(-1)).to(torch.bfloat16).float().cpu()         # [H,V] bf16-rounded, on the host for the draws
+        ids = []
+        for step in range(k):
+            toks = []
+            for hi in range(min(num_heads, k - step)):
+                lg = logits[hi].view(1, 1, -1)
+                if temperature > 0:
+                    lg = lg / temperature
+                toks.append(torch.multinomial(torch.softmax(lg, dim=-1).squeeze(1), 1))
+            ids.append(toks[0])
+        d_ids = torch.cat(ids, dim=1).to("cuda")
+        d_logits = logits[0].view(1, 1, -1).expand(1, k, -1).contiguous().to("cuda")
+        return d_ids, d_logits
+
+    def _decode_host_policy(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int,
+                            temperature: float = 0.7):
         """The reference's verification for the logit-threshold policies (speculative_scheduler.py:294-368, policies.py:213-396;
         pipeline.py:1019-1100 and :2397-3030): per row and step, K greedy draft tokens with their logits, the base model's
         OWN K greedy tokens with their logits from the same prefix (K one-token HIP forwards each, over the rows' cached
@@ -333,8 +371,10 @@ class SpeculativePipeline:
                 raise ValueError("empty prompt")
         eos = self.base_lm.get_tokenizer_info().get("eos_token_id")
         n = len(rows)
+        medusa = self._medusa_random()
         for lm in (self.base_lm, self.draft_lm):
-            lm.clear_kv_cache()
+            if lm is not None:
+                lm.clear_kv_cache()
         stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
         step = 0
         while any(r.active for r in rows):
@@ -349,7 +389,10 @@ class SpeculativePipeline:
                 if not r.active:
                     continue
                 ids = torch.tensor([r.seq], dtype=torch.long)
-                d_ids, d_logits = self.draft_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
+                if medusa:
+                    d_ids, d_logits = self._draft_medusa_random(r.seq, k, temperature, b, n)
+                else:
+                    d_ids, d_logits = self.draft_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
                 b_ids, b_logits = self.base_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
                 a, _info = self.policy.accept_tokens(d_ids, b_ids, d_logits, b_logits)
                 d, t = d_ids[0].tolist(), b_ids[0].tolist()
@@ -406,8 +449,9 @@ class SpeculativePipeline:
         ids = self._encode(prompt)
         # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
         # drafts with the draft model
-        if self.policy_name != "longest_prefix":
-            rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens)
+        if self.policy_name != "longest_prefix" or self._medusa_random():
+            rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
+                                                temperature=float(temperature))
         else:
             rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
                                     self_draft=self.config.get("draft_mode") in ("medusa", "eagle"))

@@ -164,6 +164,29 @@ class HipLM(LanguageModel):
             return (torch.empty((1, 0), dtype=torch.long, device=dev), torch.empty((1, 0, self.vocab_size), dtype=torch.float32, device=dev))
         return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
 
+    def last_hidden_state(self, input_ids: torch.Tensor, row: int = 0, rows: int = 1) -> torch.Tensor:
+        """`outputs.hidden_states[-1][:, -1:]` of the reference's draft modes (pipeline.py:674-686): the hidden state of
+        the LAST token after the final norm, fp32 [1][1][d] with bf16-representable values. The prefix is cached as in
+        generate_tokens; one 1-token forward with the head skipped leaves the residual row (sd_model_hidden_rows), and
+        the final norm is applied here with the roundings of the engine's own fused norm (csrc/gemv.hip prologue)."""
+        ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
+        ids = validate_and_clamp_tokens(ids.long(), self.vocab_size, "last_hidden_state")
+        self._generate_row(ids, 0, row, max(rows, row + 1))          # caches ids[:-1] in cache row `row`
+        m, dev, L = self._model, self._device, ids.shape[1]
+        m.forward(ids[:, -1:].to(dev, torch.int32).contiguous(), torch.full((1,), L - 1, dtype=torch.int32, device=dev), 0,
+                  skip_head=True, row0=row)
+        x = m.hidden_rows(1).float()                                  # [1][d]
+        w = self.weights
+        bf = lambda t: t.to(torch.bfloat16).float()
+        if self.config.arch == W.ARCH_LLAMA:
+            xn = bf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.config.norm_eps))
+            h = bf(xn * w.final_norm_w.float())
+        else:
+            mean = x.mean(-1, keepdim=True)
+            var = ((x * x).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0)
+            h = bf((x - mean) * torch.rsqrt(var + self.config.norm_eps) * w.final_norm_w.float() + w.final_norm_b.float())
+        return h.view(1, 1, -1)
+
     def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor):
         """The K-token parallel verify as a wrapper call: one forward over
         (last, d_1..d_K) -> (argmax ids [B, K+1], logits [B, K+1, V])."""

@@ -401,3 +401,27 @@ def test_logit_threshold_policies_match_oracle_and_reference():
     got, want = pipe.generate_batch(prompts, max_tokens=10, do_sample=False), oracle.generate_batch(prompts, 10)
     for a, b in zip(got, want):
         assert a["generated_tokens"] == b["generated_tokens"] and (a["proposed"], a["accepted"]) == (b["proposed"], b["accepted"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 4])
+def test_medusa_random_heads_as_the_reference_pipeline_runs_them(k):
+    """draft_mode='medusa' with head_init 'random' = the reference PIPELINE's Medusa mode (_run_medusa_hf, pipeline.py:655-763):
+    fresh random heads and multinomial draws from the global torch generator every step, over the target's last hidden
+    state from the HIP engine. Under torch.manual_seed the run equals the oracle's replay of the generator (which is pinned
+    to the reference's own runs, tests/test_oracle_pipeline.py) token for token."""
+    from src.specdec import HipLM, SpeculativePipeline
+
+    drf, tgt = tiny_pair()
+    prompt = synthetic_prompts(1, 9, tgt.config.vocab)[0].tolist()
+    pipe = SpeculativePipeline(base_lm=HipLM(tgt.to("cuda")), draft_model="none", draft_mode="medusa", controller="fixed",
+                               controller_params={"k": k}, seed=1234)
+    pipe.config["medusa"] = {"enabled": True, "num_heads": 2, "head_init": "random", "temperature": 0.7, "top_p": 1.0}
+    torch.manual_seed(777 + k)
+    got = pipe.generate(prompt, max_tokens=10, temperature=0.7, do_sample=False)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), None, k=k, eos_token_id=tgt.config.eos_token_id, draft_mode="medusa_random",
+                            medusa_num_heads=2, medusa_temperature=0.7)
+    torch.manual_seed(777 + k)
+    want = oracle.generate(prompt, 10)
+    assert got["generated_tokens"] == want["generated_tokens"]
+    assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
+    assert got["proposed"] == k * got["steps"]
