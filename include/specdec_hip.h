@@ -86,7 +86,9 @@ int sd_verify_prefix(const void* logits, int logits_dtype,
  * the cumulative weights; draw index = draw_counters[b] (then incremented) or draw0 when
  * draw_counters is NULL; stream = stream_id[b] or b. top_k in 1..1024; top_k <= 0 with
  * top_p >= 1 draws from the whole row (Gumbel-max, one Philox value per element); top_k <= 0
- * with top_p < 1 is refused. Asynchronous on `stream`, no allocation, graph-capturable. */
+ * with top_p < 1 is the full-vocabulary nucleus (the reference with top_k = None): the row is
+ * consumed in rank blocks of 1024 (exact radix select per block) until the cumulative probability
+ * — over the softmax of the WHOLE row — passes top_p. Asynchronous on `stream`, no allocation, graph-capturable. */
 int sd_sample_token(const void* logits, int logits_dtype, int64_t row_stride, int B, int V,
                     const int32_t* pos, int rows_per_b, const int32_t* active, float temperature,
                     int top_k, float top_p, uint64_t seed, uint32_t* draw_counters, uint32_t draw0,

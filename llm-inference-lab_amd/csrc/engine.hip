@@ -875,7 +875,6 @@ extern "C" int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperat
   const size_t need = static_cast<size_t>(s->B) * (s->K + 1) * s->target->cfg.vocab * 2;
   SD_REQUIRE(logits_bytes >= need, "specdec_set_sampling: logits buffer %zu B < %zu B ([B][K+1][V] bf16)", logits_bytes, need);
   SD_REQUIRE(temperature == temperature && temperature >= 0.f, "specdec_set_sampling: temperature %g", temperature);
-  SD_REQUIRE(top_k > 0 || !(top_p < 1.0f), "specdec_set_sampling: top_p=%g needs top_k (full-vocabulary nucleus is not supported)", top_p);
   SD_REQUIRE(top_k <= 0 || (top_k < s->target->cfg.vocab ? top_k : s->target->cfg.vocab) <= 1024, "specdec_set_sampling: top_k=%d > 1024", top_k);
   s->sample = 1;
   s->temperature = temperature;

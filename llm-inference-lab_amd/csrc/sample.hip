@@ -22,7 +22,7 @@
 //
 // Without top-k and top-p the draw is a Gumbel-max over the whole row (one Philox value per
 // element, block argmax): no ordered prefix sum over 128 K probabilities.
-// Full-vocabulary nucleus sampling (top_p < 1 without top_k) needs a full sort and is refused.
+// Full-vocabulary nucleus sampling (top_p < 1 without top_k): sample_nucleus_kernel below, rank blocks of 1024.
 
 #include "engine.h"
 
@@ -293,6 +293,262 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const Sampl
   }
 }
 
+// ------------------------------------------------------------------------------
+// Full-vocabulary nucleus sampling: top_p < 1 WITHOUT top_k (sample_bonus_token_from_logits with top_k = None,
+// src/specdec/core/pipeline.py:105-125: sort the whole row, cumulative softmax, drop a token when the inclusive
+// cumulative probability exceeds top_p, the first is always kept). No full sort here: the row is consumed in RANK BLOCKS
+// of 1024 — an exact radix select (5 passes over the L2-resident row) finds the composite key of rank 1024 (r+1), the
+// elements between it and the previous block's key are gathered and sorted in LDS, and thread 0 continues the cumulative
+// sum where the previous block stopped. A peaked distribution (any trained model) ends inside the first block; a flat one
+// walks on, 1024 ranks at a time, up to the whole vocabulary. Arithmetic as oracle/sampling_ref.py (float64):
+//   v_i = x_i / T, m = max v, e_i = exp(v_i - m),
+//   Z   = sum_s ( sum_j e[s + 1024 j] )  — per-slot sums s = 0..1023 (j ascending), then the slots in order,
+//   cum += e_i / Z in sorted order; kept while i == 0 or !(cum > top_p); the draw inverts one Philox uniform through
+//   the kept weights in sorted order.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSampleThreads) void sample_nucleus_kernel(const SampleArgs a) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint64_t sel[kSampleThreads];
+  __shared__ double ev[kSampleThreads];
+  __shared__ uint32_t s_cnt, s_digit, s_above;
+  __shared__ double s_z, s_cum, s_z2, s_target, s_c;
+  __shared__ int s_done, s_keep, s_pick;
+  __shared__ uint64_t s_best;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.active && a.active[b] == 0) return;
+  const int rowi = b * a.rows_per_b + (a.pos ? a.pos[b] : 0);
+  const char* row = static_cast<const char*>(a.logits) + static_cast<size_t>(rowi) * a.row_stride * (a.dtype == SD_F32 ? 4 : 2);
+  const int V = a.V;
+  const double T = static_cast<double>(a.temperature);
+  const bool scale = (a.temperature > 0.f) && (a.temperature != 1.0f);
+  auto scaled = [&](int i) {
+    double v = static_cast<double>(load_logit(row, a.dtype, i));
+    return scale ? v / T : v;
+  };
+  constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
+  auto key_index = [&](uint64_t c) { return static_cast<int>(kIdxMask - static_cast<uint32_t>(c & kIdxMask)); };
+
+  // ---- the top element (largest composite key) and the normaliser
+  if (tid == 0) s_best = 0;
+  __syncthreads();
+  {
+    uint64_t best = 0;
+    for (int i = tid; i < V; i += kSampleThreads) {
+      const uint64_t c = composite_key(load_logit(row, a.dtype, i), i);
+      best = c > best ? c : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(&s_best), static_cast<unsigned long long>(best));
+  }
+  __syncthreads();
+  const int top_idx = key_index(s_best);
+  const double m = scaled(top_idx);
+  const bool finite = (m == m) && (m - m == 0.0);
+  if (!finite) {                       // -inf / NaN / +inf on top: the reference falls back to argmax (:129-131)
+    if (tid == 0) {
+      a.out[b] = top_idx;
+      if (a.draw) a.draw[b] = a.draw[b] + 1u;
+    }
+    return;
+  }
+  {
+    double p = 0.0;
+    for (int i = tid; i < V; i += kSampleThreads) {
+      double e = exp(scaled(i) - m);
+      if (e != e) e = 0.0;
+      p += e;
+    }
+    ev[tid] = p;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double z = 0.0;
+    for (int s2 = 0; s2 < kSampleThreads; ++s2) z += ev[s2];
+    s_z = z;
+    s_cum = 0.0;
+    s_z2 = 0.0;
+    s_keep = 0;
+    s_done = 0;
+  }
+  __syncthreads();
+
+  // exact composite key of rank k (1-based from the top): radix select over all 52 bits
+  auto select_kth = [&](int k) -> uint64_t {
+    const int widths[5] = {11, 11, 10, 10, 10};
+    uint64_t prefix = 0;
+    int decided = 0, need = k;
+    for (int p = 0; p < 5; ++p) {
+      const int w = widths[p];
+      const int shift = 52 - decided - w;
+      for (int i = tid; i < 2048; i += kSampleThreads) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += kSampleThreads) {
+        const uint64_t c = composite_key(load_logit(row, a.dtype, i), i);
+        if ((c >> (shift + w)) == prefix) atomicAdd(&hist[(c >> shift) & ((1u << w) - 1u)], 1u);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const int nb = 1 << w;
+        uint32_t local = 0;
+        for (int j = 0; j < 32; ++j) {
+          const int d = lane * 32 + j;
+          if (d < nb) local += hist[d];
+        }
+        uint32_t incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_down(incl, off, 64);
+          if (lane + off < 64) incl += o;
+        }
+        uint32_t above = incl - local;
+        if (above < static_cast<uint32_t>(need) && incl >= static_cast<uint32_t>(need)) {
+          for (int j = 31; j >= 0; --j) {
+            const int d = lane * 32 + j;
+            if (d >= nb) continue;
+            const uint32_t h = hist[d];
+            if (above + h >= static_cast<uint32_t>(need)) {
+              s_digit = d;
+              s_above = above;
+              break;
+            }
+            above += h;
+          }
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << w) | s_digit;
+      decided += w;
+      need -= static_cast<int>(s_above);
+      __syncthreads();
+    }
+    return prefix;
+  };
+  // block r: the elements of ranks (1024 r, min(1024 (r+1), V)], sorted descending into sel[] / ev[]; returns their count
+  auto load_block = [&](int r, uint64_t upper_excl, uint64_t& thr_out) -> int {
+    const int k_hi = min((r + 1) * kSampleThreads, V);
+    const uint64_t thr = select_kth(k_hi);
+    thr_out = thr;
+    if (tid == 0) s_cnt = 0;
+    sel[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < V; i += kSampleThreads) {
+      const uint64_t c = composite_key(load_logit(row, a.dtype, i), i);
+      if (c >= thr && c < upper_excl) {
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+        if (slot < static_cast<uint32_t>(kSampleThreads)) sel[slot] = c + 1;
+      }
+    }
+    __syncthreads();
+    for (int size = 2; size <= kSampleThreads; size <<= 1) {        // descending bitonic sort of the 1024 slots (0 = empty, last)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (tid < kSampleThreads / 2) {
+          const int lo = 2 * tid - (tid & (stride - 1));
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const uint64_t x = sel[lo], y = sel[hi];
+          if ((x < y) == desc) { sel[lo] = y; sel[hi] = x; }
+        }
+        __syncthreads();
+      }
+    }
+    const int n = k_hi - r * kSampleThreads;
+    if (tid < n) {
+      const int idx = key_index(sel[tid] - 1);
+      double e = exp(scaled(idx) - m);
+      if (e != e) e = 0.0;
+      ev[tid] = e;
+      sel[tid] = static_cast<uint64_t>(idx);
+    }
+    __syncthreads();
+    return n;
+  };
+
+  // ---- phase A: how many tokens the nucleus keeps, and their total weight
+  const double tp = static_cast<double>(a.top_p);
+  const int n_blocks = (V + kSampleThreads - 1) / kSampleThreads;
+  uint64_t upper = ~0ull;
+  int blocks_used = 0;
+  for (int r = 0; r < n_blocks; ++r) {
+    uint64_t thr;
+    const int n = load_block(r, upper, thr);
+    upper = thr;
+    blocks_used = r + 1;
+    if (tid == 0) {
+      double cum = s_cum, z2 = s_z2;
+      int keep = s_keep, done = 0;
+      for (int i = 0; i < n; ++i) {
+        cum += ev[i] / s_z;
+        if ((r == 0 && i == 0) || !(cum > tp)) {
+          ++keep;
+          z2 += ev[i];
+        } else {
+          done = 1;
+          break;
+        }
+      }
+      s_cum = cum;
+      s_z2 = z2;
+      s_keep = keep;
+      s_done = done;
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+  // ---- phase B: invert one uniform through the kept weights, in sorted order
+  if (tid == 0) {
+    const uint32_t d = a.draw ? a.draw[b] : a.draw0;
+    const uint32_t sid = a.stream_id ? static_cast<uint32_t>(a.stream_id[b]) : static_cast<uint32_t>(b);
+    uint32_t r0;
+    philox4x32_10(d, sid, 0u, kTagCdf, a.seed_lo, a.seed_hi, r0);
+    s_target = static_cast<double>(r0) * 2.3283064365386963e-10 * s_z2;  // 2^-32
+    s_c = 0.0;
+    s_pick = -1;
+  }
+  __syncthreads();
+  const int n_keep = s_keep;
+  if (blocks_used == 1) {              // the common case: block 0 is still in LDS
+    if (tid == 0) {
+      int pick = n_keep - 1;
+      double c = 0.0;
+      for (int i = 0; i < n_keep; ++i) {
+        c += ev[i];
+        if (s_target < c) { pick = i; break; }
+      }
+      s_pick = static_cast<int>(sel[pick]);
+    }
+  } else {
+    upper = ~0ull;
+    int last_tok = top_idx;
+    for (int r = 0; r * kSampleThreads < n_keep; ++r) {
+      uint64_t thr;
+      const int n = load_block(r, upper, thr);
+      upper = thr;
+      const int lim = min(n, n_keep - r * kSampleThreads);
+      if (tid == 0) {
+        double c = s_c;
+        for (int i = 0; i < lim; ++i) {
+          c += ev[i];
+          if (s_target < c) { s_pick = static_cast<int>(sel[i]); break; }
+        }
+        s_c = c;
+      }
+      last_tok = static_cast<int>(sel[lim - 1]);   // (every thread reads the same LDS word)
+      __syncthreads();
+      if (s_pick >= 0) break;
+    }
+    if (tid == 0 && s_pick < 0) s_pick = last_tok;  // target == total weight (rounding): the last kept token
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.out[b] = s_pick;
+    if (a.draw) a.draw[b] = a.draw[b] + 1u;
+  }
+}
+
 __device__ __forceinline__ bool better_d(double v, int i, double bv, int bi) {
   const bool vn = (v != v), bn = (bv != bv);
   if (vn | bn) {
@@ -349,8 +605,9 @@ int launch_sample(const SampleArgs& a, int B, hipStream_t st) {
   if (a.top_k > 0) {
     SD_REQUIRE((a.top_k < a.V ? a.top_k : a.V) <= kSampleMaxK, "sample: top_k=%d > %d is not supported", a.top_k, kSampleMaxK);
     hipLaunchKernelGGL(sample_topk_kernel, dim3(B), dim3(kSampleThreads), 0, st, a);
+  } else if (a.top_p < 1.0f) {
+    hipLaunchKernelGGL(sample_nucleus_kernel, dim3(B), dim3(kSampleThreads), 0, st, a);
   } else {
-    SD_REQUIRE(!(a.top_p < 1.0f), "sample: top_p=%g without top_k (full-vocabulary nucleus sampling) is not supported", a.top_p);
     hipLaunchKernelGGL(sample_gumbel_kernel, dim3(B), dim3(kSampleThreads), 0, st, a);
   }
   SD_LAUNCH_CHECK();

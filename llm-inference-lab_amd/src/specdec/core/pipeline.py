@@ -418,6 +418,59 @@ class SpeculativePipeline:
         stats["k"] = int(getattr(self.controller, "k", 0) or 0)
         return rows, stats
 
+    def _decode_rejection(self, prompts: List[List[int]], max_tokens: int, step_limit: int):
+        """policy="rejection" (opt-in speculative sampling, policies.RejectionSamplingPolicy; generate_batch): per row and
+        step K draft tokens DRAWN from the draft's distribution (one HIP forward each over the row's cached prefix), ONE
+        K+1-token parallel verify pass of the target over them, the accept test on the device logits, the correction /
+        bonus token drawn from the distribution the policy returns. Every uniform comes from the policy's generator."""
+        t_start = time.time()
+        pol = self.policy
+        pol.reseed()
+        rows = [_Row(list(p)) for p in prompts]
+        eos = self.base_lm.get_tokenizer_info().get("eos_token_id")
+        n = len(rows)
+        for lm in (self.base_lm, self.draft_lm):
+            lm.clear_kv_cache()
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
+        step = 0
+        while any(r.active for r in rows):
+            step += 1
+            ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
+                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+            k = int(self.controller.get_k(step, ctx))
+            if k <= 0:
+                break
+            for b, r in enumerate(rows):
+                if not r.active:
+                    continue
+                drafted, d_logits = [], []
+                for _ in range(k):
+                    _, lg = self.draft_lm.generate_tokens(torch.tensor([r.seq + drafted], dtype=torch.long), 1, do_sample=False, row=b, rows=n)
+                    d_logits.append(lg[:, 0])
+                    drafted.append(pol.draw(pol.distributions(lg[0, 0]), float(pol.uniforms(1)[0])))
+                d_ids = torch.tensor([drafted], dtype=torch.long, device="cuda")
+                _, b_logits = self.base_lm.verify_tokens(torch.tensor([r.seq], dtype=torch.long), d_ids, row=b, rows=n)
+                a, info = pol.accept_tokens(d_ids, d_ids, torch.stack(d_logits, dim=1), b_logits)
+                nxt = pol.draw(info["next_distribution"], float(pol.uniforms(1)[0]))
+                emitted = drafted[:a] + [nxt]
+                if eos is not None and eos in emitted:
+                    emitted = emitted[: emitted.index(eos) + 1]
+                    r.active = False
+                r.seq = r.seq + emitted
+                r.generated.extend(emitted)
+                r.proposed += k
+                r.accepted += a + 1                        # the bonus / correction token counted, as generate_batch counts it
+                r.steps += 1
+                stats["proposed"] += k
+                stats["accepted"] += a + 1
+                if len(r.generated) >= max_tokens or r.steps >= step_limit:
+                    r.active = False
+        torch.cuda.synchronize()
+        stats["steps"] = max((r.steps for r in rows), default=0)
+        stats["total_ms"] = (time.time() - t_start) * 1e3
+        stats["k"] = int(getattr(self.controller, "k", 0) or 0)
+        return rows, stats
+
     # ------------------------------------------------------------------ public API
     def _sampling_config(self, do_sample: bool, temperature: float, kwargs: Dict[str, Any]) -> Optional[Dict[str, Any]]:
         """Sampler parameters of a do_sample=True run (kwargs over config, pipeline.py:3148-3153)."""
@@ -425,9 +478,6 @@ class SpeculativePipeline:
             return None
         top_p = kwargs.get("top_p", self.config.get("top_p", None))
         top_k = kwargs.get("top_k", self.config.get("top_k", None))
-        if (not top_k or top_k <= 0) and top_p is not None and top_p < 1.0:
-            raise NotImplementedError("do_sample=True with top_p < 1 and no top_k: full-vocabulary nucleus sampling is "
-                                      "not on the HIP path (pass top_k <= 1024, or top_p=1.0)")
         if top_k and min(int(top_k), self.base_lm.vocab_size) > 1024:
             raise NotImplementedError(f"do_sample=True: top_k={top_k} > 1024 is not on the HIP path")
         return {"temperature": float(temperature), "top_k": int(top_k) if top_k else None,
@@ -449,6 +499,8 @@ class SpeculativePipeline:
         ids = self._encode(prompt)
         # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
         # drafts with the draft model
+        if self.policy_name == "rejection":
+            raise NotImplementedError("policy='rejection' is a generate_batch policy (it emits a correction / bonus token every step)")
         if self.policy_name != "longest_prefix" or self._medusa_random():
             rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
                                                 temperature=float(temperature))
@@ -487,7 +539,9 @@ class SpeculativePipeline:
         if self.draft_lm is None and not heads:
             raise ValueError("generate_batch drafts with the draft model (the reference ignores draft_mode there): pass draft_lm / draft_model")
         ids = [self._encode(p) for p in prompts]
-        if self.policy_name != "longest_prefix":
+        if self.policy_name == "rejection":
+            rows, st = self._decode_rejection(ids, max_tokens, step_limit=max_tokens)   # sampling IS the policy
+        elif self.policy_name != "longest_prefix":
             if sampling is not None:
                 raise NotImplementedError(f"policy={self.policy_name!r} with do_sample=True is not on the HIP path")
             rows, st = self._decode_host_policy(ids, max_tokens, HipSpecDec.EMIT_BONUS, step_limit=max_tokens)

@@ -187,18 +187,22 @@ class HipLM(LanguageModel):
             h = bf((x - mean) * torch.rsqrt(var + self.config.norm_eps) * w.final_norm_w.float() + w.final_norm_b.float())
         return h.view(1, 1, -1)
 
-    def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor):
+    def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor, row: Optional[int] = None, rows: int = 1):
         """The K-token parallel verify as a wrapper call: one forward over
-        (last, d_1..d_K) -> (argmax ids [B, K+1], logits [B, K+1, V])."""
+        (last, d_1..d_K) -> (argmax ids [B, K+1], logits [B, K+1, V]). `row` (one sequence): cache row to use."""
         ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
         B, L = ids.shape
-        K = draft_tokens.shape[1]
-        self.generate_tokens(ids, 0)  # caches the prefix
-        m = self._model
         dev = self._device
+        if row is None:
+            self.generate_tokens(ids, 0)  # caches the prefix
+            row0 = 0
+        else:
+            self._generate_row(validate_and_clamp_tokens(ids.long(), self.vocab_size, "verify_tokens"), 0, row, max(rows, row + 1))
+            row0 = row
+        m = self._model
         toks = torch.cat([ids[:, -1:].to(dev), draft_tokens.to(dev)], dim=1).to(torch.int32).contiguous()
         pos = torch.full((B,), L - 1, dtype=torch.int32, device=dev)
-        t_ids, logits = m.forward(toks, pos, 0, want_logits=True, logits_dtype=torch.float32)
+        t_ids, logits = m.forward(toks, pos, 0, want_logits=True, logits_dtype=torch.float32, row0=row0)
         return t_ids.long(), logits
 
     def get_tokenizer_info(self) -> Dict[str, Any]:

@@ -154,12 +154,72 @@ class TypicalAcceptancePolicy(AcceptancePolicy):
         return {"policy": self.name, "p": self.p}
 
 
+class RejectionSamplingPolicy(AcceptancePolicy):
+    """Speculative-sampling acceptance (opt-in; NOT in the reference, whose four policies are deterministic — SURVEY
+    section 8 f1): draft token d_i, drawn from the draft distribution q_i, is accepted with probability
+    min(1, p_i(d_i) / q_i(d_i)) where p_i is the target distribution at that position GIVEN the draft tokens before it (the
+    K+1-token parallel verify pass provides exactly that); the first rejected position is re-drawn from
+    normalise(max(0, p - q)), a fully accepted step draws a bonus token from p_K. The emitted sequence is then distributed
+    exactly as the target's own sampling (Leviathan et al. 2023, Chen et al. 2023).
+
+    `temperature` shapes both distributions (softmax(logits / T)); the uniforms come from a private generator seeded with
+    `seed` (or are passed in: `uniforms=`), so a run is reproducible and a CPU restatement (oracle/hostlogic_ref.py:
+    rejection_accept) replays it. All arithmetic is float64 on the tensors' device."""
+
+    def __init__(self, temperature: float = 1.0, seed: int = 0):
+        self.temperature = float(temperature)
+        self.seed = int(seed)
+        self.name = "rejection"
+        self._gen = torch.Generator().manual_seed(self.seed)
+
+    def reseed(self, seed: Optional[int] = None) -> None:
+        self._gen = torch.Generator().manual_seed(self.seed if seed is None else int(seed))
+
+    def uniforms(self, n: int) -> torch.Tensor:
+        return torch.rand(n, generator=self._gen, dtype=torch.float64)
+
+    def distributions(self, logits: torch.Tensor) -> torch.Tensor:
+        t = self.temperature if self.temperature > 0 else 1.0
+        return torch.softmax(logits.double() / t, dim=-1)
+
+    def accept_tokens(self, proposed_tokens, base_tokens, proposed_logits=None, base_logits=None, **kwargs):
+        if proposed_logits is None or base_logits is None:
+            raise ValueError("rejection sampling needs the draft and the target logits")
+        n = proposed_tokens.shape[1]
+        u = kwargs.get("uniforms")
+        u = self.uniforms(n) if u is None else torch.as_tensor(u, dtype=torch.float64)
+        p = self.distributions(base_logits[0, :n])                      # [K, V] target, conditioned on the draft prefix
+        q = self.distributions(proposed_logits[0, :n])
+        idx = proposed_tokens[0, :n].to(p.device).long().unsqueeze(-1)
+        ratio = (p.gather(-1, idx) / q.gather(-1, idx)).squeeze(-1)     # q(d) > 0: d was drawn from q
+        accepted_len = _first_false((u.to(ratio.device) < ratio).tolist())
+        if accepted_len < n:
+            resid = (p[accepted_len] - q[accepted_len]).clamp_min(0.0)
+            total = resid.sum()
+            nxt = resid / total if float(total) > 0 else p[accepted_len]
+        else:                                                            # bonus: the target's distribution after all K drafts
+            nxt = self.distributions(base_logits[0, n]) if base_logits.shape[1] > n else None
+        return accepted_len, {"policy": self.name, "accepted_len": accepted_len, "proposed_len": n, "temperature": self.temperature,
+                              "ratios": ratio.tolist(), "next_distribution": nxt}
+
+    @staticmethod
+    def draw(dist: torch.Tensor, u: float) -> int:
+        """Inverse-CDF draw in index order."""
+        c = torch.cumsum(dist.double(), dim=-1)
+        i = int(torch.searchsorted(c, torch.tensor(float(u) * float(c[-1]), dtype=torch.float64, device=c.device), right=True))
+        return min(i, dist.numel() - 1)
+
+    def get_info(self):
+        return {"policy": self.name, "temperature": self.temperature, "seed": self.seed}
+
+
 def create_policy(policy_name: str, **kwargs: Any) -> AcceptancePolicy:
     makers = {
         "longest_prefix": LongestPrefixPolicy,
         "conf_threshold": lambda: ConfidenceThresholdPolicy(kwargs.get("tau", 0.5)),
         "topk_agree": lambda: TopKAgreementPolicy(kwargs.get("k", 5)),
         "typical": lambda: TypicalAcceptancePolicy(kwargs.get("p", 0.9)),
+        "rejection": lambda: RejectionSamplingPolicy(kwargs.get("temperature", 1.0), kwargs.get("seed", 0)),
     }
     if policy_name not in makers:
         raise ValueError(f"Unknown policy: {policy_name}. Available: {list(makers.keys())}")

@@ -50,6 +50,35 @@ def typical_accept(draft_ids, base_logits, p: float) -> int:
     return _leading_true((probs.gather(-1, ids.unsqueeze(-1)).squeeze(-1) >= p).tolist())
 
 
+def rejection_accept(draft_ids, draft_logits, base_logits, uniforms, temperature: float = 1.0):
+    """Speculative-sampling acceptance (not in the reference: the product's opt-in `rejection` policy, restated in
+    numpy float64): accept d_i while u_i < p_i(d_i) / q_i(d_i); -> (accepted_len, distribution of the next token:
+    normalise(max(0, p - q)) at the first rejection, p_K after a full acceptance, None if base_logits has no K-th row)."""
+    d = np.asarray(draft_ids).reshape(-1)
+    n = d.size
+    t = temperature if temperature > 0 else 1.0
+
+    def sm(x):
+        x = np.asarray(x, dtype=np.float64) / t
+        e = np.exp(x - x.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+
+    bl = np.asarray(base_logits, dtype=np.float64).reshape(-1, np.asarray(base_logits).shape[-1])
+    p, q = sm(bl[:n]), sm(np.asarray(draft_logits, dtype=np.float64).reshape(-1, bl.shape[-1])[:n])
+    a = 0
+    for i in range(n):
+        if float(uniforms[i]) < p[i, d[i]] / q[i, d[i]]:
+            a += 1
+        else:
+            break
+    if a < n:
+        r = np.maximum(p[a] - q[a], 0.0)
+        nxt = r / r.sum() if r.sum() > 0 else p[a]
+    else:
+        nxt = sm(bl[n]) if bl.shape[0] > n else None
+    return a, nxt
+
+
 # ---- adaptive K (src/specdec/policies/controllers.py:63-141) -------------------------------------
 class AdaptiveKOracle:
     def __init__(self, initial_k=4, min_k=1, max_k=8, step_size=1, window_size=32, target_acceptance_rate=0.7):

@@ -19,6 +19,9 @@ e = exp(scaled - max), sums sequential in sorted order), so the only operation t
 IEEE-exact on both sides is `exp`. The kept set and its probabilities are pinned against draws of
 the reference function itself (tests/golden/hostlogic_golden.json: "sampling").
 
+Full-vocabulary nucleus sampling (top_p < 1 without top_k) is `nucleus_distribution`: the same rule over the whole sorted
+row, with the normaliser summed in an order a 1024-thread workgroup reproduces (pinned by "sampling_nucleus" draws).
+
 With neither top-k nor top-p the draw is a Gumbel-max over the whole vocabulary (one Philox value
 per element): the same categorical distribution without any ordered prefix sum.
 """
@@ -116,15 +119,56 @@ def filtered_distribution(logits: np.ndarray, temperature: float, top_k: Optiona
     return idx[:n_keep], e[:n_keep]
 
 
+NUCLEUS_SLOTS = 1024
+
+
+def nucleus_distribution(logits: np.ndarray, temperature: float, top_p: float) -> Tuple[np.ndarray, np.ndarray]:
+    """Full-vocabulary nucleus (top_k = None, top_p < 1; pipeline.py:105-125): -> (token ids of the kept tokens in sorted
+    order, their float64 weights e_i). The cumulative probability runs over the softmax of the WHOLE row. The normaliser is
+    summed in the order the device kernel can reproduce: slot s = i mod 1024 collects its elements in index order, the 1024
+    slot sums are added in slot order."""
+    x = np.asarray(logits, dtype=np.float32).reshape(-1)
+    V = x.shape[0]
+    order = sorted_top_k(x, V)
+    T = float(np.float32(temperature))
+    vals = x.astype(np.float64)
+    if T > 0 and T != 1.0:
+        vals = vals / T
+    m = vals[order[0]]
+    if not np.isfinite(m):
+        return order[:1], np.ones(1)
+    with np.errstate(invalid="ignore"):
+        e_all = np.exp(vals - m)
+    e_all = np.where(np.isnan(e_all), 0.0, e_all)
+    z = 0.0
+    for s in range(min(NUCLEUS_SLOTS, V)):
+        p = 0.0
+        for v in e_all[s::NUCLEUS_SLOTS]:
+            p += v
+        z += p
+    tp = float(np.float32(top_p))
+    e = e_all[order]
+    cum, n_keep = 0.0, 0
+    for i in range(V):
+        cum += e[i] / z
+        if i == 0 or not (cum > tp):
+            n_keep = i + 1
+        else:
+            break
+    return order[:n_keep], e[:n_keep]
+
+
 def sample_token_ref(logits: np.ndarray, temperature: float, top_k: Optional[int], top_p: Optional[float],
                      seed: int, draw: int, stream: int) -> int:
     """One sampled token id (do_sample=True)."""
     x = np.asarray(logits, dtype=np.float32).reshape(-1)
     if (not top_k or top_k <= 0):
         if top_p is not None and float(np.float32(top_p)) < 1.0:
-            raise NotImplementedError("top_p without top_k: full-vocabulary nucleus sampling is not restated")
-        return gumbel_argmax_ref(x, temperature, seed, draw, stream)
-    ids, e = filtered_distribution(x, temperature, top_k, top_p)
+            ids, e = nucleus_distribution(x, temperature, top_p)
+        else:
+            return gumbel_argmax_ref(x, temperature, seed, draw, stream)
+    else:
+        ids, e = filtered_distribution(x, temperature, top_k, top_p)
     z = 0.0
     for v in e:
         z += v

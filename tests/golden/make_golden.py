@@ -459,6 +459,26 @@ def gen_hostlogic():
             counts[t] = counts.get(t, 0) + 1
         out["sampling"].append({"seed": seed, "V": V, "scale": scale, "bf16": case % 5 == 4, "top_k": top_k, "top_p": top_p,
                                 "temperature": temp, "n_draws": n_draws, "counts": {str(k): v for k, v in sorted(counts.items())}})
+    # full-vocabulary nucleus (top_k = None, top_p < 1: pipeline.py:105-125 over the whole sorted row)
+    out["sampling_nucleus"] = []
+    nrng = np.random.default_rng(91)
+    for case in range(8):
+        V = int(nrng.choice([300, 700, 1500, 2600]))
+        seed = 9900 + case
+        scale = float(nrng.choice([1.0, 3.0, 6.0]))
+        logits = torch.from_numpy(np.random.default_rng(seed).standard_normal(V).astype(np.float32)) * scale
+        if case % 4 == 3:
+            logits = logits.to(torch.bfloat16).float()
+        top_p = float(nrng.choice([0.95, 0.9, 0.6, 0.3]))
+        temp = float(nrng.choice([1.0, 0.7, 1.5]))
+        n_draws = 4000
+        torch.manual_seed(5151 + case)
+        counts = {}
+        for _ in range(n_draws):
+            t = int(sample_bonus_token_from_logits(logits, temp, True, top_p=top_p, top_k=None, vocab_size=V)[0])
+            counts[t] = counts.get(t, 0) + 1
+        out["sampling_nucleus"].append({"seed": seed, "V": V, "scale": scale, "bf16": case % 4 == 3, "top_p": top_p, "temperature": temp,
+                                        "n_draws": n_draws, "counts": {str(k): v for k, v in sorted(counts.items())}})
     with open(os.path.join(OUT, "hostlogic_golden.json"), "w") as f:
         json.dump(out, f)
     print("hostlogic goldens:", {k: len(v) for k, v in out.items()})

@@ -425,3 +425,47 @@ def test_medusa_random_heads_as_the_reference_pipeline_runs_them(k):
     assert got["generated_tokens"] == want["generated_tokens"]
     assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
     assert got["proposed"] == k * got["steps"]
+
+
+def test_rejection_sampling_policy_in_the_pipeline():
+    """policy='rejection' (opt-in speculative sampling, not one of the reference's policies): the run equals a CPU replay —
+    OracleLM logits, oracle/hostlogic_ref.rejection_accept, the same uniform stream — and with draft == target every
+    draft token is accepted (p / q = 1)."""
+    from oracle.hostlogic_ref import rejection_accept
+    from src.specdec import HipLM, SpeculativePipeline
+    from src.specdec.policies.policies import RejectionSamplingPolicy
+
+    drf, tgt = cases.policy_pair(torch.bfloat16)
+    blm, dlm = HipLM(tgt.to("cuda")), HipLM(drf.to("cuda"))
+    k, mt, seed, temp = 3, 12, 21, 0.8
+    prompt = [9, 40, 77, 101, 5, 66]
+    pipe = SpeculativePipeline(base_lm=blm, draft_lm=dlm, policy="rejection", policy_params={"temperature": temp, "seed": seed},
+                               controller="fixed", controller_params={"k": k}, seed=1234)
+    got = pipe.generate_batch([prompt], max_tokens=mt, do_sample=True)[0]
+    # CPU replay
+    base, draft = OracleLM(tgt, "bf16"), OracleLM(drf, "bf16")
+    ref = RejectionSamplingPolicy(temp, seed)
+    seq, gen, proposed, accepted = list(prompt), [], 0, 0
+    while len(gen) < mt:
+        drafted, dl = [], []
+        for _ in range(k):
+            lg, _ = draft.forward(torch.tensor([seq + drafted]))
+            dl.append(lg[0, -1])
+            drafted.append(ref.draw(ref.distributions(lg[0, -1]), float(ref.uniforms(1)[0])))
+        lg, _ = base.forward(torch.tensor([seq + drafted]))
+        bl = lg[0, len(seq) - 1:]
+        a, nxt = rejection_accept(drafted, torch.stack(dl).numpy(), bl.numpy(), ref.uniforms(k).numpy(), temp)
+        tok = ref.draw(torch.from_numpy(nxt), float(ref.uniforms(1)[0]))
+        emitted = drafted[:a] + [tok]
+        if 2 in emitted:
+            emitted = emitted[: emitted.index(2) + 1]
+            seq, gen = seq + emitted, gen + emitted
+            proposed, accepted = proposed + k, accepted + a + 1
+            break
+        seq, gen, proposed, accepted = seq + emitted, gen + emitted, proposed + k, accepted + a + 1
+    assert got["generated_tokens"] == gen
+    assert (got["proposed"], got["accepted"]) == (proposed, accepted)
+    same = SpeculativePipeline(base_lm=blm, draft_lm=blm, policy="rejection", policy_params={"temperature": temp, "seed": 3},
+                               controller="fixed", controller_params={"k": k}, seed=1234).generate_batch([prompt], max_tokens=mt, do_sample=True)[0]
+    steps = same["batch_metrics"]["total_steps"]
+    assert same["accepted"] == (k + 1) * steps or 2 in same["generated_tokens"]

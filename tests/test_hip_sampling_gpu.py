@@ -66,6 +66,36 @@ def test_ties_special_values_and_flat_rows():
                 assert _hip(x, T, top_k, top_p, 5, draw, 0) == want, (name, top_k, top_p, T, draw)
 
 
+@pytest.mark.parametrize("V,scale,top_p,T", [(300, 3.0, 0.9, 1.0), (2600, 1.0, 0.95, 0.7), (5000, 0.2, 0.6, 1.5), (128256, 4.0, 0.9, 0.7),
+                                              (128256, 0.05, 0.3, 1.0), (4099, 6.0, 0.3, 0.7)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_vocabulary_nucleus_matches_oracle(V, scale, top_p, T, dtype):
+    """top_p < 1 without top_k (the reference with top_k = None, pipeline.py:105-125): kept sets from a handful of tokens
+    to tens of thousands (the flat V = 128256 row keeps ~38 k tokens: 38 rank blocks), token for token against
+    oracle/sampling_ref.py, which is pinned by draws of the reference function ("sampling_nucleus")."""
+    g = torch.Generator().manual_seed(V + int(scale * 100))
+    x = (torch.randn(V, generator=g) * scale).to(dtype)
+    xs = x.float().numpy()
+    n_keep = len(S.nucleus_distribution(xs, T, top_p)[0])
+    for draw in range(4):
+        want = S.sample_token_ref(xs, T, None, top_p, 11, draw, 2)
+        assert _hip(x, T, None, top_p, 11, draw, 2) == want, (V, scale, top_p, T, dtype, draw, n_keep)
+
+
+def test_nucleus_special_rows():
+    ninf = torch.full((777,), float("-inf"))
+    ninf[5] = 1.0
+    ninf[600] = 0.5
+    nan = torch.randn(500, generator=torch.Generator().manual_seed(1))
+    nan[77] = float("nan")
+    const = torch.full((3000,), 0.25)
+    for name, x in (("ninf", ninf), ("nan", nan), ("const", const)):
+        for top_p in (0.9, 0.5):
+            for draw in range(3):
+                want = S.sample_token_ref(x.numpy(), 0.7, None, top_p, 5, draw, 0)
+                assert _hip(x, 0.7, None, top_p, 5, draw, 0) == want, (name, top_p, draw)
+
+
 def test_gumbel_path_rows_counters_and_refusals():
     from specdec_hip import _abi
     from specdec_hip.ops import sample_token_hip
@@ -87,8 +117,6 @@ def test_gumbel_path_rows_counters_and_refusals():
             row = lg[b * R + int(pos[b])].float().numpy()
             assert int(out[b]) == S.sample_token_ref(row, 0.9, top_k, top_p, 77, int(counters[b]), 10 + b), (top_k, b)
         assert c.cpu().tolist() == [1, 5, 9, 3, 101]
-    with pytest.raises(_abi.HipLibraryError, match="top_p"):
-        sample_token_hip(lg.cuda(), 0.9, None, 0.9)
     with pytest.raises(_abi.HipLibraryError, match="top_k"):
         sample_token_hip(lg.cuda(), 0.9, 2000, 0.9)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -177,7 +205,9 @@ def test_sampled_default_config_and_refusals():
     oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=tgt.config.eos_token_id)
     want = oracle.generate_batch(prompts, 16, sampling={"temperature": 0.7, "top_k": 50, "top_p": 0.9, "seed": 1234})
     assert [r["generated_tokens"] for r in got] == [r["generated_tokens"] for r in want]
-    with pytest.raises(NotImplementedError, match="top_k"):
-        pipe.generate_batch(prompts, max_tokens=4, do_sample=True, top_k=None, top_p=0.9)
+    # top_k = None with top_p < 1: the full-vocabulary nucleus inside the captured step
+    got = pipe.generate_batch(prompts, max_tokens=12, do_sample=True, top_k=None, top_p=0.9)
+    want = oracle.generate_batch(prompts, 12, sampling={"temperature": 0.7, "top_k": None, "top_p": 0.9, "seed": 1234})
+    assert [r["generated_tokens"] for r in got] == [r["generated_tokens"] for r in want]
     with pytest.raises(NotImplementedError, match="generate_batch"):
         pipe.generate(prompts[0], max_tokens=4, do_sample=True)

@@ -3,6 +3,8 @@ outputs of the reference's own functions (tests/golden/hostlogic_golden.json), p
 known-answer cases of the reference's unit tests."""
 
 import json
+
+import numpy as np
 import os
 
 import pytest
@@ -167,3 +169,43 @@ def test_deterministic_mode(monkeypatch):
     assert torch.equal(b, torch.rand(2))
     monkeypatch.setenv("SPECDEC_DETERMINISTIC", "0")
     assert ensure_deterministic() is False
+
+
+def test_rejection_sampling_policy_matches_restatement_and_preserves_the_target_distribution():
+    """The opt-in `rejection` policy (speculative sampling; not one of the reference's policies): (a) product == the numpy
+    restatement on seeded logits and uniforms — accepted length and the distribution of the next token; (b) the defining
+    property: one draft token drawn from q, accepted / corrected by the policy, is distributed as the target p."""
+    from scipy.stats import chisquare
+
+    from oracle.hostlogic_ref import rejection_accept
+    from src.specdec.policies.policies import RejectionSamplingPolicy, create_policy
+
+    rng = np.random.default_rng(3)
+    for case in range(20):
+        K, V = int(rng.integers(1, 6)), int(rng.integers(5, 60))
+        dl = torch.from_numpy(rng.standard_normal((1, K, V)).astype(np.float32)) * 2
+        bl = torch.from_numpy(rng.standard_normal((1, K + 1, V)).astype(np.float32)) * 2
+        bl[0, :K] += dl[0] * float(rng.uniform(0, 2))          # correlated target: some accepts, some rejects
+        temp = float(rng.choice([1.0, 0.7, 1.5]))
+        pol = create_policy("rejection", temperature=temp, seed=case)
+        q = pol.distributions(dl[0])
+        d_ids = torch.tensor([[RejectionSamplingPolicy.draw(q[i], rng.random()) for i in range(K)]])
+        u = rng.random(K)
+        a, info = pol.accept_tokens(d_ids, d_ids, dl, bl, uniforms=u)
+        wa, wnext = rejection_accept(d_ids[0].numpy(), dl[0].numpy(), bl[0].numpy(), u, temp)
+        assert a == wa and info["policy"] == "rejection"
+        assert np.allclose(info["next_distribution"].numpy(), wnext, rtol=1e-12, atol=1e-15)
+    # (b) V = 6, K = 1: emitted token ~ p
+    V, n = 6, 20000
+    dl = torch.tensor([[[1.0, 0.2, -0.5, 2.0, 0.0, -1.0]]])
+    bl = torch.tensor([[[0.0, 1.5, 0.3, 0.5, -2.0, 1.0], [0.0] * 6]])
+    pol = create_policy("rejection", temperature=1.0, seed=9)
+    q, p = pol.distributions(dl[0, 0]), pol.distributions(bl[0, 0])
+    counts = np.zeros(V)
+    uu = np.random.default_rng(10).random((n, 3))
+    for i in range(n):
+        d = RejectionSamplingPolicy.draw(q, uu[i, 0])
+        a, info = pol.accept_tokens(torch.tensor([[d]]), torch.tensor([[d]]), dl, bl, uniforms=[uu[i, 1]])
+        tok = d if a == 1 else RejectionSamplingPolicy.draw(info["next_distribution"], uu[i, 2])
+        counts[tok] += 1
+    assert chisquare(counts, p.numpy() * n).pvalue > 1e-4
