@@ -49,17 +49,20 @@ PROMPT_SUITE = [
 ]
 
 
-def system_info():
+def system_info(batch_size: int = 1, deterministic: bool = True):
+    """Keys of the reference's get_system_info + run metadata (comprehensive_k_sweep.py:130-206, :1006-1013), plus this
+    build's own (`hip`, `env`)."""
     from kernels import get_kernel_info
 
-    info = {
-        "timestamp": datetime.now().isoformat(), "python": platform.python_version(), "torch": torch.__version__,
-        "hip": torch.version.hip, "platform": platform.platform(), "device": "cuda",
-        "gpu": torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
-        "dtype": "bfloat16", "kernel_backends": get_kernel_info(),
-        "env": {k: v for k, v in os.environ.items() if k.startswith("SPECDEC_")},
+    kinfo = get_kernel_info()
+    return {
+        "timestamp": datetime.now().isoformat(), "python_version": platform.python_version(), "pytorch_version": torch.__version__,
+        "platform": platform.platform(), "device": "cuda", "cuda_available": torch.cuda.is_available(), "mps_available": False,
+        "device_name": torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
+        "dtype": "bfloat16", "kernel_backends": kinfo, "kernel_info": kinfo, "deterministic": bool(deterministic),
+        "batch_size": int(batch_size), "kv_append_enabled": True, "cuda_graph": True, "parallel_streams": True,
+        "hip": torch.version.hip, "env": {k: v for k, v in os.environ.items() if k.startswith("SPECDEC_")},
     }
-    return info
 
 
 def prompt_ids(lm, text, idx):
@@ -74,11 +77,13 @@ def prompt_ids(lm, text, idx):
     return torch.randint(4, lm.vocab_size, (n,), generator=g).tolist()
 
 
-def run(args):
+def run(args, base=None, draft=None):
+    """`base` / `draft`: ready HipLM objects (tests); else built from args.base_model / args.draft_model."""
     from specdec import SpeculativePipeline, create_hip_lm
 
-    base = create_hip_lm(args.base_model)
-    draft = create_hip_lm(args.draft_model) if not args.share_draft_embeddings else None
+    base = base or create_hip_lm(args.base_model)
+    if draft is None and not args.share_draft_embeddings:
+        draft = create_hip_lm(args.draft_model)
     if draft is None:
         from specdec_hip import weights as W
         from specdec.models.hip_lm import HipLM
@@ -93,6 +98,7 @@ def run(args):
         pipe = SpeculativePipeline(base_lm=base, draft_lm=draft, max_draft=k, controller="fixed",
                                    controller_params={"k": k}, seed=1234)
         pipe.generate(prompt_ids(base, "Hello", 99), max_tokens=4, do_sample=False)  # warm-up (:365)
+        sample = bool(getattr(args, "do_sample", False))
         k_rows = []
         for it in range(args.iterations):
             for b0 in range(0, len(PROMPT_SUITE), batch):
@@ -103,23 +109,24 @@ def run(args):
                         continue
                     idxs = list(range(len(PROMPT_SUITE)))
                     prompts = [prompt_ids(base, PROMPT_SUITE[i], i) for i in idxs]
-                    outs = pipe.generate_many(prompts, max_tokens=args.max_tokens, batch_size=batch, do_sample=False)
+                    outs = pipe.generate_many(prompts, max_tokens=args.max_tokens, batch_size=batch, do_sample=sample)
                     for o in outs:
                         o.setdefault("kv_appended_tokens", o["num_generated"])
                         o.setdefault("kv_append_time_ms", 0.0)
                 else:
-                    outs = pipe.generate_batch(prompts, max_tokens=args.max_tokens, temperature=0.7, do_sample=False)
+                    outs = pipe.generate_batch(prompts, max_tokens=args.max_tokens, temperature=0.7, do_sample=sample)
                 for i, r in zip(idxs, outs):
                     row = {
                         "k": k, "iteration": it + 1, "prompt_idx": i + 1, "prompt_name": PROMPT_SUITE[i],
                         "prompt": PROMPT_SUITE[i], "prompt_text": PROMPT_SUITE[i], "completion_text": r["text"],
+                        "full_text": PROMPT_SUITE[i] + " " + r["text"],
                         "completion_token_count": len(r["generated_tokens"]), "latency_ms": r["latency_ms"],
                         "tokens_per_sec": r["tokens_per_sec"], "acceptance_rate": r["acceptance_rate"],
                         "proposed": r["proposed"], "accepted": r["accepted"],
                         "kv_appended_tokens": r.get("kv_appended_tokens", 0), "kv_append_time_ms": r["kv_append_time_ms"],
                         "kv_append_enabled": r["kv_append_enabled"], "kv_append_backend": r["kv_append_backend"],
-                        "text": r["text"][:100], "device": "cuda", "dtype": "bfloat16",
-                        "generated_tokens": r["generated_tokens"],
+                        "text": r["text"][:100], "success": True, "device": "cuda", "dtype": "bfloat16",
+                        "batch_size": batch, "generated_tokens": r["generated_tokens"],   # (generated_tokens: extra to the reference's keys)
                     }
                     k_rows.append(row)
                     detailed.append(row)
@@ -146,7 +153,7 @@ def run(args):
     return results, detailed
 
 
-def save(results, detailed, out_dir):
+def save(results, detailed, out_dir, batch_size: int = 1):
     ts = datetime.now().strftime("%Y%m%d_%H%M%S")
     out = Path(out_dir)
     out.mkdir(parents=True, exist_ok=True)
@@ -156,7 +163,7 @@ def save(results, detailed, out_dir):
         w.writeheader()
         w.writerows(results)
     with open(json_file, "w") as f:
-        json.dump({"system_info": system_info(), "summary_results": results, "detailed_results": detailed,
+        json.dump({"system_info": system_info(batch_size), "summary_results": results, "detailed_results": detailed,
                    "detailed_metrics": {}}, f, indent=2)
     return csv_file, json_file
 
@@ -174,11 +181,12 @@ if __name__ == "__main__":
     ap.add_argument("--batch-size", type=int, default=1)
     ap.add_argument("--continuous", action="store_true",
                     help="continuous batching (generate_many) instead of the reference harness' fixed batches")
+    ap.add_argument("--do-sample", action="store_true", help="sampled bonus token (T = 0.7, the reference script's setting) instead of greedy")
     ap.add_argument("--output-dir", default="gpurun_out/k_sweep")
     a = ap.parse_args()
     if not a.draft_model.startswith("synthetic:"):
         a.share_draft_embeddings = False
     t0 = time.time()
     res, det = run(a)
-    c, j = save(res, det, a.output_dir)
+    c, j = save(res, det, a.output_dir, int(os.getenv("SPECDEC_BATCH_SIZE", str(a.batch_size))))
     print(f"saved {c} and {j} in {time.time() - t0:.1f}s")

@@ -30,8 +30,11 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--seed", type=int)
     ap.add_argument("--device", type=str, choices=["auto", "cuda"], default="auto")
     ap.add_argument("--impl", type=str, choices=["hip"], default="hip")
-    ap.add_argument("--draft-mode", type=str, choices=["vanilla"], default="vanilla")
-    ap.add_argument("--policy", type=str, choices=["longest_prefix"], default="longest_prefix")
+    ap.add_argument("--draft-mode", type=str, choices=["vanilla", "medusa", "eagle"], default="vanilla")
+    ap.add_argument("--policy", type=str, choices=["longest_prefix", "conf_threshold", "topk_agree", "typical"], default="longest_prefix")
+    ap.add_argument("--policy-tau", type=float, help="conf_threshold: tau")
+    ap.add_argument("--policy-k", type=int, help="topk_agree: k")
+    ap.add_argument("--policy-p", type=float, help="typical: p")
     ap.add_argument("--controller", type=str, choices=["fixed", "adaptive"], default="fixed")
     ap.add_argument("--K", type=int, default=4, help="K of the fixed controller")
     ap.add_argument("--adaptive-K", action="store_true")
@@ -56,7 +59,8 @@ def main(argv=None) -> int:
     try:
         pipe = SpeculativePipeline(config_path=args.config, base_model=args.base_model, draft_model=args.draft_model,
                                    max_draft=args.max_draft, device=args.device, seed=args.seed, implementation=args.impl,
-                                   policy=args.policy, controller=controller, controller_params=cp, draft_mode=args.draft_mode)
+                                   policy=args.policy, controller=controller, controller_params=cp, draft_mode=args.draft_mode,
+                                   policy_params={k: v for k, v in (("tau", args.policy_tau), ("k", args.policy_k), ("p", args.policy_p)) if v is not None})
         r = pipe.generate(prompt=args.prompt, max_tokens=args.max_tokens, temperature=args.temperature, do_sample=False)
     except Exception as e:  # the reference CLI reports and exits 1 (run_specdec.py:276-278)
         logging.error("Error: %s", e)

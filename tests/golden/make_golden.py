@@ -383,6 +383,56 @@ def gen_pipeline_policies():
         json.dump(out, f, indent=1, default=str)
 
 
+def gen_harness():
+    """Result-file schema of the reference's K-sweep harness (scripts/comprehensive_k_sweep.py:209-1060): the harness itself
+    is run on the local tiny G8 pair (CPU, 6 new tokens, 1 iteration, K = 1..2) and the KEYS and value types of what it
+    returns and writes are stored — summary rows (one per K: the CSV header), detailed rows (one per prompt), the JSON
+    top level and `system_info`. Values are not stored (timings)."""
+    import shutil
+    import tempfile
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    os.environ.pop("SPECDEC_DRY_RUN", None)
+    _reference_pipeline_class()
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    import comprehensive_k_sweep as H
+
+    assert os.path.abspath(H.__file__).startswith(os.path.abspath(REF) + os.sep)
+    d, t = cases.g8_pairs(torch.float32)["structured"]
+    tmp = tempfile.mkdtemp(prefix="g8h_")
+    cwd = os.getcwd()
+    try:
+        ddir, tdir = os.path.join(tmp, "draft"), os.path.join(tmp, "target")
+        _save_local_hf_llama(d, ddir)
+        _save_local_hf_llama(t, tdir)
+        os.chdir(tmp)
+        results, detailed, meta = H.run_comprehensive_k_sweep(base_model=tdir, draft_model=ddir, max_tokens=6, iterations=1, device="cpu",
+                                                               deterministic=True, max_k=2)
+        sysinfo = H.get_system_info("cpu")
+        sysinfo.update(meta)
+        csv_file, json_file = H.save_results(results, detailed, sysinfo, os.path.join(tmp, "out"), "cpu")
+        with open(json_file) as f:
+            written = json.load(f)
+        with open(csv_file) as f:
+            header = f.readline().strip().split(",")
+
+        def kinds(row):
+            return {k: type(v).__name__ for k, v in row.items()}
+
+        out = {"summary_row": kinds(results[0]), "detailed_row": kinds(detailed[0]), "n_summary_rows": len(results),
+               "n_detailed_rows": len(detailed), "csv_header": header, "json_top_level": sorted(written.keys()),
+               "system_info_keys": sorted(written["system_info"].keys()),
+               "file_name_patterns": [os.path.basename(str(csv_file))[:12] + "<timestamp>.csv", os.path.basename(str(json_file))[:12] + "<timestamp>.json"],
+               "prompt_suite": list(H.PROMPT_SUITE) if hasattr(H, "PROMPT_SUITE") else sorted({r.get("prompt", "") for r in detailed})}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "harness_schema_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+    print("harness schema:", len(out["summary_row"]), "summary keys,", len(out["detailed_row"]), "detailed keys")
+
+
 def gen_hostlogic():
     """G3-G6: the reference's host-side pieces on seeded inputs (policies, bonus-token
     filtering, controllers, sequence utils, token validation)."""
@@ -501,3 +551,5 @@ if __name__ == "__main__":
         gen_medusa()
     if "policies" in which:
         gen_pipeline_policies()
+    if "harness" in which:
+        gen_harness()
