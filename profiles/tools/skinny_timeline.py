@@ -14,7 +14,7 @@ tokens = [int(t) for t in sys.argv[2:]] or [20, 40]
 mw = W.synthetic_llama(preset, seed=0, device="cuda")
 hm = HipModel(mw, batch=1, l_max=64)
 st = torch.cuda.Stream()
-for which in (0, 2, 4):
+for which in [int(w) for w in os.environ.get("PROBE_WHICH", "0,2,4").split(",")]:
     for T in tokens:
         us, nb = hm.probe_gemv(which, T=T, iters=40, stream=st)
         print(f"which={which} T={T}: {us:.1f} us", flush=True)
