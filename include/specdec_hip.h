@@ -310,6 +310,26 @@ int sd_specdec_set_sampling(sd_specdec* s, int enable, float temperature, int to
                             uint64_t seed, void* logits_buf, size_t logits_bytes,
                             uint32_t* draw_counters, const int32_t* stream_ids);
 
+/* Per-row adaptive K inside the captured step ("AdaptiveKController driving per-row K inside a
+ * captured graph"; the rule is the reference's AdaptiveKController.get_k, src/specdec/policies/controllers.py:100-126,
+ * which the reference applies to one K for the whole batch from the host, pipeline.py:1994-2014). The loop keeps the
+ * SHAPE K it was created with (= max_k): every step still drafts and verifies K positions per row, but for row b only
+ * the first k_row[b] proposals count — accept length = min(longest matching prefix, k_row[b]), emitted tokens and the
+ * bonus token follow from that length exactly as in a step run at K = k_row[b] — and after the accept scan the device
+ * applies the controller rule to the row's own counters (accepted / proposed so far, strict), so the next step can
+ * be launched without a host round trip. History starts as [0.0] (the reference's first get_k reports rate 0.0), the
+ * mean of the last four rates is compared with target_rate +- 0.1, K moves by step_size inside [min_k, max_k];
+ * double arithmetic in the reference's order. Requires 1 <= min_k <= initial_k <= max_k <= K. The step record gains a
+ * last int per row: the k that counted in that step (K when adaptive K is off). enable = 0 returns to fixed K.
+ * Either call drops the captured graph. Not available with persistent Medusa heads / EAGLE-lite. */
+int sd_specdec_set_adaptive(sd_specdec* s, int enable, int initial_k, int min_k, int max_k, int step_size,
+                            double target_rate, void* stream);
+/* (Re)write row b's controller state: a new sequence in the row's slot (k = initial_k, 0, 0, hist = NULL -> [0.0]), or
+ * the host's in-order view after its rules overrode steps that had been launched ahead. `hist`: hist_n <= 4 rates,
+ * oldest first. Asynchronous on `stream` (synchronises it first: one pinned staging slot per row). */
+int sd_specdec_set_adaptive_row(sd_specdec* s, int b, int k, int accepted, int proposed, int hist_n,
+                                const double* hist, void* stream);
+
 /* EAGLE-lite drafting (the reference's _run_eagle_hf, src/specdec/core/pipeline.py:765-889, under greedy decoding), for
  * a loop created with draft = NULL: every step runs a 1-token target forward for the residual row of the last token,
  * h_t = final_norm(row); extrapolates K hidden rows h_1 = h_t + alpha (h_t - E), h_2 = h_1 + alpha (h_1 - h_t), ...
@@ -355,6 +375,7 @@ int sd_specdec_sync(sd_specdec* s, void* stream);
  *   [3 .. 3+K]            emitted tokens (n_new valid, -1 padded)
  *   [4+K .. 3+2K]         draft tokens d_1..d_K
  *   [4+2K .. 4+3K]        target argmax t_0..t_K
+ *   [5+3K]                proposals that counted for the row in this step (K unless sd_specdec_set_adaptive)
  * row stride = sd_specdec_record_ints(). */
 const int32_t* sd_specdec_record(const sd_specdec* s);
 int sd_specdec_record_ints(const sd_specdec* s);

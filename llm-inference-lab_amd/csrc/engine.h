@@ -23,6 +23,15 @@ struct SpecState {
   int32_t* n_new;       // [B]
   int32_t* new_tok;     // [B][K+1] emitted tokens, -1 padded
   int32_t* sampled;     // [B]   sampled token for position accept_len (sampling mode), else unused
+  // per-row adaptive K (sd_specdec_set_adaptive): the rule of AdaptiveKController (controllers.py:63-141) per row, on
+  // the device, so that the next step never waits for the host. K above stays the SHAPE of the step (max_k).
+  int adaptive;         // 0 = every row proposes K
+  int a_min, a_max, a_step;
+  double a_hi, a_lo;    // target_acceptance_rate + 0.1 / - 0.1 (computed by the host in double, as the reference does)
+  int32_t* k_row;       // [B]    proposals that count for the row in the NEXT step
+  int32_t* ctl;         // [B][4] accepted so far, proposed so far, history length (<= 4), k of the step just done
+  double* ctl_hist;     // [B][4] the last four reported acceptance rates, oldest first
+  int32_t* k_active;    // [1]    max k_row over the active rows
 };
 
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);

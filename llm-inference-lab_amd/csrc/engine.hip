@@ -584,6 +584,8 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
 }
 
 // ---------------------------------------------------------------------------- step loop
+static constexpr int kStageInts = 24;   // per row: 8 ints of set_row, then (accepted, proposed, hist_n, k) + 4 doubles
+
 struct sd_specdec {
   sd_model* draft = nullptr;
   sd_model* target = nullptr;
@@ -594,7 +596,8 @@ struct sd_specdec {
   int32_t* host_record = nullptr;  // pinned, device-accessible: [2 slots][B][rec]
   hipEvent_t ev_done[2] = {nullptr, nullptr};   // recorded after launch i on the target stream (i & 1)
   long launches = 0;
-  int32_t* host_stage = nullptr;  // pinned staging for set_row
+  int32_t* host_stage = nullptr;  // pinned staging for set_row / set_adaptive_row: [B][kStageInts]
+  int a_initial = 0;
   int rec = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipGraph_t graph = nullptr;
@@ -643,6 +646,13 @@ __global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t
       r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
     }
     if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
+    if (lane == 0) r[5 + 3 * K] = s.adaptive ? s.ctl[4 * b + 3] : K;   // proposals that counted for the row in this step
+  }
+  if (s.adaptive) {   // widest row of the next step
+    int ka = 0;
+    for (int b = lane; b < s.B; b += kWave) ka = max(ka, s.active[b] ? s.k_row[b] : 0);
+    for (int off = 32; off > 0; off >>= 1) ka = max(ka, __shfl_xor(ka, off, 64));
+    if (lane == 0) *s.k_active = ka;
   }
   if (lane == 0) *step_counter = *step_counter + 1;
 }
@@ -779,9 +789,10 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   s->B = B;
   s->K = K;
   s->mode = emit_mode;
-  s->rec = 5 + 3 * K;
+  s->rec = 6 + 3 * K;
   const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1) + 1);
-  const size_t n_total = n_state + 4;
+  const size_t n_adapt = static_cast<size_t>(B) * (1 + 4 + 8) + 2 + 2;   // k_row, ctl, ctl_hist (doubles), k_active (+ alignment)
+  const size_t n_total = n_state + 4 + n_adapt;
   hipError_t e = hipMalloc(&s->dev_block, n_total * sizeof(int32_t));
   if (e != hipSuccess) {
     delete s;
@@ -804,11 +815,17 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   st.n_new = p; p += B;
   st.new_tok = p; p += static_cast<size_t>(B) * (K + 1);
   st.sampled = p; p += B;
-  s->step_counter = p;
+  s->step_counter = p; p += 4;
+  if ((p - s->dev_block) & 1) ++p;         // the doubles below: 8-byte aligned (hipMalloc is 256-byte aligned)
+  st.ctl_hist = reinterpret_cast<double*>(p); p += static_cast<size_t>(B) * 8;
+  st.ctl = p; p += static_cast<size_t>(B) * 4;
+  st.k_row = p; p += B;
+  st.k_active = p; p += 1;
+  st.adaptive = 0;
   if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * 2 * B * s->rec, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * 8, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * kStageInts, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
     sd_specdec_destroy(s);
@@ -843,7 +860,7 @@ extern "C" int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_to
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the staging slot of row b must not be rewritten while a previous copy is in flight
   SD_HIP_CHECK(hipStreamSynchronize(st));
-  int32_t* h = s->host_stage + b * 8;
+  int32_t* h = s->host_stage + b * kStageInts;
   h[0] = seq_len - 1;  // cur_len: position of `last`
   h[1] = active ? 1 : 0;
   h[2] = prev_tok;
@@ -852,6 +869,67 @@ extern "C" int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_to
   SD_HIP_CHECK(hipMemcpyAsync(s->st.active + b, h + 1, 4, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.tok2 + 2 * b, h + 2, 8, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.verify_tok + static_cast<size_t>(b) * (s->K + 1), h + 3, 4, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+// Per-row adaptive K. The captured step keeps the shape K = max_k; row b's proposals past k_row[b]
+// do not count (accept length clamped, bonus token = the target's token after the clamped prefix), and accept_kernel
+// moves k_row[b] by the reference's rule. enable: all rows restart (k = initial_k, history = [0.0] — the reference's
+// first get_k call reports acceptance_rate 0.0 before any step).
+extern "C" int sd_specdec_set_adaptive(sd_specdec* s, int enable, int initial_k, int min_k, int max_k, int step_size,
+                                       double target_rate, void* stream) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_set_adaptive: NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (s->exec) {   // the captured kernels hold the loop state by value
+    (void)hipGraphExecDestroy(s->exec);
+    (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+  }
+  if (!enable) {
+    s->st.adaptive = 0;
+    return 0;
+  }
+  SD_REQUIRE(min_k >= 1 && min_k <= max_k && max_k <= s->K, "specdec_set_adaptive: need 1 <= min_k (%d) <= max_k (%d) <= K of the loop (%d)", min_k, max_k, s->K);
+  SD_REQUIRE(initial_k >= min_k && initial_k <= max_k, "specdec_set_adaptive: initial_k %d outside [%d, %d]", initial_k, min_k, max_k);
+  SD_REQUIRE(step_size >= 1, "specdec_set_adaptive: step_size %d", step_size);
+  SD_REQUIRE(target_rate == target_rate, "specdec_set_adaptive: target rate is NaN");
+  SD_REQUIRE(s->heads.empty() && !s->eagle, "specdec_set_adaptive: stateful draft modes keep a fixed K");
+  s->st.adaptive = 1;
+  s->st.a_min = min_k;
+  s->st.a_max = max_k;
+  s->st.a_step = step_size;
+  s->st.a_hi = target_rate + 0.1;
+  s->st.a_lo = target_rate - 0.1;
+  s->a_initial = initial_k;
+  for (int b = 0; b < s->B; ++b)
+    if (int rc = sd_specdec_set_adaptive_row(s, b, initial_k, 0, 0, 1, nullptr, st)) return rc;
+  SD_HIP_CHECK(hipMemsetAsync(s->st.k_active, 0, 4, st));
+  return 0;
+}
+
+// (Re)write one row's controller state — a new sequence in the row's slot, or the host's in-order view after the host
+// rules overrode steps that were launched ahead. hist: hist_n <= 4 rates, oldest first (NULL: [0.0]).
+extern "C" int sd_specdec_set_adaptive_row(sd_specdec* s, int b, int k, int accepted, int proposed, int hist_n, const double* hist,
+                                           void* stream) {
+  clear_error();
+  SD_REQUIRE(s && s->st.adaptive, "specdec_set_adaptive_row: adaptive K is not enabled");
+  SD_REQUIRE(b >= 0 && b < s->B, "specdec_set_adaptive_row: row %d out of range", b);
+  SD_REQUIRE(k >= s->st.a_min && k <= s->st.a_max, "specdec_set_adaptive_row: k=%d outside [%d, %d]", k, s->st.a_min, s->st.a_max);
+  SD_REQUIRE(hist_n >= 0 && hist_n <= 4 && accepted >= 0 && proposed >= 0, "specdec_set_adaptive_row: bad counters");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SD_HIP_CHECK(hipStreamSynchronize(st));   // the staging slot must not be rewritten under a copy in flight
+  int32_t* h = s->host_stage + b * kStageInts + 8;
+  double* hd = reinterpret_cast<double*>(h + 4);
+  h[0] = accepted;
+  h[1] = proposed;
+  h[2] = hist ? hist_n : 1;
+  h[3] = k;
+  for (int i = 0; i < 4; ++i) hd[i] = (hist && i < hist_n) ? hist[i] : 0.0;
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.ctl + 4 * b, h, 16, hipMemcpyHostToDevice, st));
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.ctl_hist + 4 * b, hd, 32, hipMemcpyHostToDevice, st));
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.k_row + b, h + 3, 4, hipMemcpyHostToDevice, st));
   return 0;
 }
 

@@ -235,7 +235,40 @@ __device__ __forceinline__ int accept_scan(const SpecState& s, int b, int lane, 
   const unsigned long long m64 = __ballot(match);
   const unsigned long long valid = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
   const unsigned long long miss = (~m64) & valid;
-  return miss ? __builtin_ctzll(miss) : K;
+  const int a = miss ? __builtin_ctzll(miss) : K;
+  return s.adaptive ? min(a, s.k_row[b]) : a;   // per-row K: proposals past k_row[b] do not count
+}
+
+// AdaptiveKController.get_k (controllers.py:100-126) for one row, fed with the row's own cumulative acceptance rate
+// (strict: accepted draft tokens / proposals that counted): history of the last four rates, their mean against the
+// band target +- 0.1, K moved by step_size inside [min_k, max_k]. Double arithmetic in the reference's order
+// (sum(h[-4:]) / 4 adds oldest first), so the host mirror (the same class, per row) agrees bit for bit.
+__device__ __forceinline__ void adaptive_update(const SpecState& s, int b, int a) {
+  int32_t* c = s.ctl + 4 * b;
+  double* h = s.ctl_hist + 4 * b;
+  const int k = s.k_row[b];
+  c[3] = k;
+  if (!s.active[b]) return;
+  c[0] += a;
+  c[1] += k;
+  const double rate = static_cast<double>(c[0]) / static_cast<double>(c[1] > 0 ? c[1] : 1);
+  int n = c[2];
+  if (n < 4) {
+    h[n++] = rate;
+  } else {
+    h[0] = h[1];
+    h[1] = h[2];
+    h[2] = h[3];
+    h[3] = rate;
+  }
+  c[2] = n;
+  if (n >= 4) {
+    const double recent = (((h[0] + h[1]) + h[2]) + h[3]) / 4.0;
+    int kn = k;
+    if (recent > s.a_hi) kn = min(k + s.a_step, s.a_max);
+    else if (recent < s.a_lo) kn = max(k - s.a_step, s.a_min);
+    s.k_row[b] = kn;
+  }
 }
 
 // sampling mode: the accept length alone, so that the sampler knows which logits row to draw from
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, in
   if (lane == 0) {
     s.accept_len[b] = a;
     s.n_new[b] = n_new;
+    if (s.adaptive) adaptive_update(s, b, a);
     if (s.active[b]) {
       const int old_last = s.tok2[b * 2 + 1];
       s.tok2[b * 2 + 0] = (n_new >= 2) ? prev_new : old_last;

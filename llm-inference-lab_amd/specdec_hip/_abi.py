@@ -84,6 +84,8 @@ SIGNATURES = {
     "sd_specdec_set_row": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "sd_specdec_set_sampling": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_int, ctypes.c_float, ctypes.c_uint64,
                                          _c_void_p, _c_size, _c_void_p, _c_void_p]),
+    "sd_specdec_set_adaptive": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_double, _c_void_p]),
+    "sd_specdec_set_adaptive_row": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_double), _c_void_p]),
     "sd_specdec_set_medusa": (_c_int, [_c_void_p, _c_int, ctypes.POINTER(_c_void_p), _c_int]),
     "sd_specdec_eagle_bytes": (_c_size, [_c_int, _c_int, _c_int]),
     "sd_specdec_set_eagle": (_c_int, [_c_void_p, ctypes.c_float, _c_void_p, _c_size]),

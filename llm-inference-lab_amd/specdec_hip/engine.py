@@ -183,7 +183,7 @@ class HipModel:
 class StepRecord:
     """Host view of one completed step (pinned memory written by the device)."""
 
-    __slots__ = ("accept_len", "n_new", "cur_len", "new_tokens", "draft_tokens", "target_ids")
+    __slots__ = ("accept_len", "n_new", "cur_len", "new_tokens", "draft_tokens", "target_ids", "k_row")
 
     def __init__(self, arr: np.ndarray, K: int):
         self.accept_len = arr[:, 0].copy()
@@ -192,6 +192,7 @@ class StepRecord:
         self.new_tokens = arr[:, 3:4 + K].copy()
         self.draft_tokens = arr[:, 4 + K:4 + 2 * K].copy()
         self.target_ids = arr[:, 4 + 2 * K:5 + 3 * K].copy()
+        self.k_row = arr[:, 5 + 3 * K].copy()      # proposals that counted per row (per-row adaptive K), else K
 
 
 class HipSpecDec:
@@ -229,6 +230,28 @@ class HipSpecDec:
         with torch.cuda.device(self.device):
             _abi.check(self.lib.sd_specdec_set_row(self.handle, b, int(seq_len), int(prev_tok), int(last_tok),
                                                    1 if active else 0, self.stream_t.cuda_stream), "sd_specdec_set_row")
+
+    def set_adaptive(self, enable: bool, initial_k: int = 4, min_k: int = 1, max_k: Optional[int] = None, step_size: int = 1,
+                     target_acceptance_rate: float = 0.7):
+        """Per-row adaptive K inside the captured step (sd_specdec_set_adaptive): the loop's K is the shape (max_k),
+        the device moves every row's own k by the reference's controller rule after each accept scan."""
+        max_k = self.K if max_k is None else int(max_k)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_set_adaptive(self.handle, 1 if enable else 0, int(initial_k), int(min_k), max_k, int(step_size),
+                                                        float(target_acceptance_rate), self.stream_t.cuda_stream), "sd_specdec_set_adaptive")
+        self.adaptive = bool(enable)
+
+    def set_adaptive_row(self, b: int, k: int, accepted: int = 0, proposed: int = 0, history: Optional[Sequence[float]] = None):
+        """Row b's controller state (new sequence: defaults; repair: the host mirror's counters and last <= 4 rates)."""
+        hist = None
+        n = 1
+        if history is not None:
+            h = [float(x) for x in history][-4:]
+            n = len(h)
+            hist = (ctypes.c_double * 4)(*(h + [0.0] * (4 - n)))
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_set_adaptive_row(self.handle, int(b), int(k), int(accepted), int(proposed), n, hist,
+                                                            self.stream_t.cuda_stream), "sd_specdec_set_adaptive_row")
 
     def set_medusa(self, heads: torch.Tensor, weight_dtype: str = "bf16"):
         """Persistent Medusa heads for a loop created with draft=None (sd_specdec_set_medusa). heads: bf16 [K][V][d];

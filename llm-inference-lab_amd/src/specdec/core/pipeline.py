@@ -68,11 +68,13 @@ def _clamp(tok: int, vocab: int) -> int:
 
 
 class _Row:
-    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws", "steps")
+    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws", "steps", "strict_acc", "strict_prop", "k_trace")
 
     def __init__(self, seq: List[int]):
         self.seq, self.generated, self.active = seq, [], True
         self.proposed = self.accepted = self.draws = self.steps = 0
+        self.strict_acc = self.strict_prop = 0     # per-row adaptive K: what the row's controller is fed with
+        self.k_trace: List[int] = []               # ... and the k that counted in each of its steps
 
 
 class SpeculativePipeline:
@@ -171,8 +173,9 @@ class SpeculativePipeline:
         return cfg
 
     # ------------------------------------------------------------------ runtime pieces
-    def _runtime(self, batch: int, need_len: int, k: int, emit_mode: int, self_draft: bool = False):
-        """Engine instances (own KV caches over the shared weights) + the step loop object."""
+    def _runtime(self, batch: int, need_len: int, k: int, emit_mode: int, self_draft: bool = False, adaptive: bool = False):
+        """Engine instances (own KV caches over the shared weights) + the step loop object (`adaptive`: the loop whose
+        rows carry their own K, a different captured step from the fixed-K loop of the same shape)."""
         key = (batch, emit_mode, self_draft)
         rt = self._runtimes.get(key)
         if rt is None or rt["l_max"] < need_len:
@@ -180,9 +183,10 @@ class SpeculativePipeline:
             rt = {"l_max": l_max, "target": self.base_lm.new_engine(batch, l_max),
                   "draft": None if self_draft else self.draft_lm.new_engine(batch, l_max), "loops": {}}
             self._runtimes[key] = rt
-        loop = rt["loops"].get(k)
+        lkey = ("adaptive", k) if adaptive else k
+        loop = rt["loops"].get(lkey)
         if loop is None:
-            loop = rt["loops"][k] = HipSpecDec(rt["draft"], rt["target"], batch, k, emit_mode)
+            loop = rt["loops"][lkey] = HipSpecDec(rt["draft"], rt["target"], batch, k, emit_mode)
             if self_draft and self.medusa_heads is not None:
                 if self.medusa_heads.n_heads != k:
                     raise ValueError(f"{self.medusa_heads.n_heads} medusa heads but K={k}")
@@ -573,6 +577,7 @@ class SpeculativePipeline:
                 "draft_avg_ms": 0.0, "verify_avg_ms": st["device_ms"] / max(st["steps"], 1),
                 "batch_metrics": batch_metrics, "kv_append_enabled": True, "kv_append_backend": "hip",
                 "kv_appended_tokens": n, "kv_append_time_ms": 0.0, "sequence": list(r.seq),
+                **({"k_trace": list(r.k_trace)} if r.k_trace else {}),     # per-row adaptive K: the k of each of the row's steps
             })
         return out
 
@@ -676,8 +681,16 @@ class DecodeSession:
         ctl = pipe.controller
         k_max = getattr(ctl, "max_k", None) or getattr(ctl, "k", 4)
         self.need = max(len(r.seq) for r in self.rows) + max_tokens + 2 * int(k_max) + 8
-        self.k = pipe._effective_k(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}), self_draft)
-        self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode, self.self_draft)
+        # per-row adaptive K: the step keeps the shape max_k, the device moves every row's own k (sd_specdec_set_adaptive)
+        self.per_row = bool(getattr(ctl, "per_row", False))
+        if self.per_row and self_draft:
+            raise NotImplementedError("per-row adaptive K needs a draft model (the self-draft modes keep a fixed K)")
+        if self.per_row:
+            self.k = int(ctl.max_k)
+            self.row_ctl = [self._new_row_controller() for _ in self.rows]
+        else:
+            self.k = pipe._effective_k(ctl.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0}), self_draft)
+        self.rt, self.loop = pipe._runtime(len(self.rows), self.need, self.k, emit_mode, self.self_draft, adaptive=self.per_row)
         # positions a row may use: the cache rows and both models' position tables
         self.pos_limit = min(self.rt["l_max"], pipe.base_lm.config.max_pos,
                              pipe.draft_lm.config.max_pos if not self_draft else pipe.base_lm.config.max_pos)
@@ -688,6 +701,14 @@ class DecodeSession:
         self.loop.join_current_stream()
         for b, r in enumerate(self.rows):
             pipe._set_row(self.loop, b, r)
+        if self.per_row:
+            params = (ctl.initial_k, ctl.min_k, ctl.max_k, ctl.step_size, ctl.target_acceptance_rate)
+            if getattr(self.loop, "_adaptive_params", None) != params:
+                self.loop.set_adaptive(True, ctl.initial_k, ctl.min_k, ctl.max_k, ctl.step_size, ctl.target_acceptance_rate)
+                self.loop._adaptive_params = params       # (enabling restarts every row; drops the captured step once)
+            else:
+                for b in range(len(self.rows)):
+                    self.loop.set_adaptive_row(b, ctl.initial_k)
         self._apply_sampling()
         self._stateful_draft = self_draft and (pipe.medusa_heads is not None or pipe._eagle())
         if self_draft and pipe._eagle():
@@ -698,7 +719,7 @@ class DecodeSession:
 
         # (persistent Medusa heads / EAGLE-lite: a void step would replace the next proposals with ones derived from stale
         # state — harmless for the tokens, but the counters would no longer be those of the in-order loop)
-        self._early = (isinstance(ctl, FixedKController) and sampling is None
+        self._early = ((isinstance(ctl, FixedKController) or self.per_row) and sampling is None
                        and not self._stateful_draft
                        and os.environ.get("SPECDEC_EARLY_LAUNCH", "1") != "0")
         self._depth = 2 if self._early else 1
@@ -711,6 +732,13 @@ class DecodeSession:
 
     def any_active(self) -> bool:
         return any(r.active for r in self.rows)
+
+    def _new_row_controller(self):
+        """The host's mirror of a row's device-side controller: the same rule, already past the reference's first get_k
+        (which reports acceptance_rate 0.0 before any step)."""
+        m = self.pipe.controller.fork()
+        m.get_k(1, {"step": 1, "generated_tokens": 0, "acceptance_rate": 0.0})
+        return m
 
     def _apply_sampling(self) -> None:
         """Loops are cached per (batch, K): (re)configure the one in use for this run."""
@@ -746,6 +774,9 @@ class DecodeSession:
                 pipe._prefill_row(rt, b, r.seq)
                 loop.join_current_stream()
             pipe._set_row(loop, b, r)              # (re)position, or freeze a finished row
+            if self.per_row:                       # the device counted steps the host voided: hand it the in-order view
+                m = self.row_ctl[b]
+                loop.set_adaptive_row(b, m.current_k, r.strict_acc, r.strict_prop, m.acceptance_history[-4:])
         self._flagged.clear()
 
     @property
@@ -788,7 +819,7 @@ class DecodeSession:
         pipe, rows, stats = self.pipe, self.rows, self.stats
         self.step += 1
         step = self.step
-        if step > 1 and not self._early:
+        if step > 1 and not self._early and not self.per_row:
             ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
                    "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
             k_new = int(pipe.controller.get_k(step, ctx))
@@ -826,6 +857,15 @@ class DecodeSession:
             t = [int(x) for x in rec.target_ids[b]]
             d = [int(x) for x in rec.draft_tokens[b]]
             before, acc0 = r.seq, r.accepted
+            if self.per_row:                    # the k that counted for this row in this step, from the device's controller
+                k = int(rec.k_row[b])
+                m = self.row_ctl[b]
+                if k != m.current_k:
+                    raise RuntimeError(f"row {b}: the device ran step {r.steps + 1} at k={k}, the host's controller says {m.current_k}")
+                r.k_trace.append(k)
+                r.strict_acc += a
+                r.strict_prop += k
+                m.get_k(r.steps + 2, {"step": r.steps + 2, "acceptance_rate": r.strict_acc / max(r.strict_prop, 1)})
             if self.sampling is not None:
                 t[a] = int(rec.new_tokens[b][a])       # the token the device sampled at position a
             assumed = before + t[: int(rec.n_new[b])]  # what the device advanced to
@@ -841,7 +881,7 @@ class DecodeSession:
             stats["accepted"] += r.accepted - acc0
             if r.active and self.step_limit is not None and r.steps >= self.step_limit:
                 r.active = False                # the reference's loop bound counts steps (pipeline.py:1984, :984)
-            if r.active and len(r.seq) + 2 * k + 4 > self.pos_limit:
+            if r.active and len(r.seq) + 2 * self.k + 4 > self.pos_limit:
                 r.active = False                # out of cache rows / model positions
             if not r.active:
                 self._flagged[b] = "freeze"     # stop the row on the device
@@ -864,6 +904,8 @@ class DecodeSession:
         if len(prompt) + self.max_tokens + 2 * self.k + 8 > self.rt["l_max"] or len(prompt) + 2 * self.k + 4 > self.pos_limit:
             raise ValueError(f"prompt of {len(prompt)} tokens does not fit this session (l_max {self.rt['l_max']}, positions {self.pos_limit})")
         self.rows[b] = _Row(list(prompt))
+        if self.per_row:
+            self.row_ctl[b] = self._new_row_controller()
         self._flagged[b] = "resync"
         for _, vs in self._queue:
             vs.add(b)

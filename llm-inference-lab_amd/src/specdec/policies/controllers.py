@@ -35,7 +35,10 @@ class AdaptiveKController(KController):
     _MIN_HISTORY = 4
 
     def __init__(self, initial_k: int = 4, min_k: int = 1, max_k: int = 8, step_size: int = 1,
-                 window_size: int = 32, target_acceptance_rate: float = 0.7):
+                 window_size: int = 32, target_acceptance_rate: float = 0.7, per_row: bool = False):
+        # per_row (not in the reference): every batch row carries its own instance of this rule,
+        # evaluated on the device inside the captured step (sd_specdec_set_adaptive); this object holds the parameters
+        self.per_row = bool(per_row)
         self.initial_k, self.min_k, self.max_k = initial_k, min_k, max_k
         self.step_size, self.window_size = step_size, window_size
         self.target_acceptance_rate = target_acceptance_rate
@@ -62,6 +65,11 @@ class AdaptiveKController(KController):
         del self.k_history[: max(0, len(self.k_history) - self.window_size)]
         return self.current_k
 
+    def fork(self) -> "AdaptiveKController":
+        """A fresh controller with the same parameters (one per batch row)."""
+        return AdaptiveKController(self.initial_k, self.min_k, self.max_k, self.step_size, self.window_size,
+                                   self.target_acceptance_rate)
+
     def get_info(self) -> Dict[str, Any]:
         return {
             "controller": self.name, "current_k": self.current_k, "min_k": self.min_k, "max_k": self.max_k,
@@ -77,6 +85,6 @@ def create_controller(controller_type: str, **kwargs: Any) -> KController:
         return AdaptiveKController(
             initial_k=kwargs.get("initial_k", 4), min_k=kwargs.get("min_k", 1), max_k=kwargs.get("max_k", 8),
             step_size=kwargs.get("step_size", 1), window_size=kwargs.get("window_size", 32),
-            target_acceptance_rate=kwargs.get("target_acceptance_rate", 0.7),
+            target_acceptance_rate=kwargs.get("target_acceptance_rate", 0.7), per_row=kwargs.get("per_row", False),
         )
     raise ValueError(f"Unknown controller: {controller_type}. Available: ['fixed', 'adaptive']")

@@ -330,7 +330,7 @@ class OraclePipeline:
 
     def generate_batch(self, prompts: Sequence[Sequence[int]], max_tokens: int,
                        max_steps: Optional[int] = None, sampling: Optional[Dict] = None,
-                       step_log: Optional[List] = None) -> List[Dict]:
+                       step_log: Optional[List] = None, per_row_k: Optional[Dict] = None) -> List[Dict]:
         """`max_steps` (not in the reference) bounds a timing sample to a number of steps; `step_log`, when given,
         receives (wall clock, tokens generated so far over all rows) after every step (bench.py times segments with it).
         `sampling` = {temperature, top_k, top_p, seed} turns on do_sample=True: drafting and
@@ -339,6 +339,20 @@ class OraclePipeline:
         if sampling is not None and self.reprefill:
             raise ValueError("sampling needs the cached verify pass (reprefill=False)")
         rows = [RowState(seq=[int(x) for x in p]) for p in prompts]
+        # per_row_k (not in the reference; the semantics of sd_specdec_set_adaptive): the step keeps
+        # the shape self.k = max_k, but every row has its own AdaptiveKController (controllers.py:63-141) fed with the
+        # row's own strict acceptance rate; only the first k_row proposals of a row count
+        ctls, strict = None, None
+        if per_row_k is not None:
+            from .hostlogic_ref import AdaptiveKOracle
+
+            if self.reprefill or self.policy != "longest_prefix":
+                raise ValueError("per-row K: cached verify pass and exact-match acceptance only")
+            ctls = [AdaptiveKOracle(**per_row_k) for _ in rows]
+            for c in ctls:
+                c.get_k({"acceptance_rate": 0.0})            # the reference's first call, before any step
+            strict = [[0, 0] for _ in rows]
+            self.k_trace = [[] for _ in rows]
         self.trace = []
         self._next_draft = {}
         self._eagle_state = {}
@@ -352,6 +366,14 @@ class OraclePipeline:
                 if not r.active:
                     continue
                 draft, t, a = self._propose_and_verify(r.seq, i)
+                k_row = self.k
+                if ctls is not None:
+                    k_row = ctls[i].k
+                    a = min(a, k_row)
+                    self.k_trace[i].append(k_row)
+                    strict[i][0] += a
+                    strict[i][1] += k_row
+                    ctls[i].get_k({"acceptance_rate": strict[i][0] / max(strict[i][1], 1)})
                 before = len(r.seq)
                 bonus_at = None
                 if sampling is not None:
@@ -362,7 +384,7 @@ class OraclePipeline:
                     def bonus_at(pos, _lg=lg_rows, _r=r, _i=i):
                         return sample_token_ref(_lg[pos], sampling["temperature"], sampling.get("top_k"), sampling.get("top_p"),
                                                 int(sampling.get("seed", 0)), _r.draws, _i)
-                appended = step_rules_batch(r, self.k, a, draft, t, max_tokens, self.eos, self.vocab, bonus_at)
+                appended = step_rules_batch(r, k_row, a, draft, t, max_tokens, self.eos, self.vocab, bonus_at)
                 if sampling is not None:
                     r.draws += 1
                 self.trace.append({"step": step, "row": i, "a": a, "draft": draft, "t": t[: a + 1],

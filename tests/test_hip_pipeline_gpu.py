@@ -115,6 +115,51 @@ def test_adaptive_controller_changes_k_mid_run():
     assert got[0]["batch_metrics"]["k"] > 2
 
 
+@pytest.mark.parametrize("early", ["1", "0"])
+def test_per_row_adaptive_k_inside_the_captured_step(early, monkeypatch):
+    """sd_specdec_set_adaptive: every row's K is moved by the reference's controller rule ON THE DEVICE (no host round trip,
+    steps launched ahead), the step keeps the shape max_k. Tokens, counters and the per-step k of every row equal the oracle
+    (one AdaptiveKController per row); the host mirror raises if the device's k ever differs from its own replay."""
+    monkeypatch.setenv("SPECDEC_EARLY_LAUNCH", early)
+    drf, tgt = tiny_pair(flip_fraction=0.35)
+    params = {"initial_k": 2, "min_k": 1, "max_k": 4, "step_size": 1, "target_acceptance_rate": 0.6}
+    pipe = _pipe(drf, tgt, 4, controller="adaptive", controller_params=dict(params, per_row=True))
+    prompts = synthetic_prompts(3, 9, 1000).tolist()
+    got = pipe.generate_batch(prompts, max_tokens=40, do_sample=False)
+    o = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=tgt.config.eos_token_id)
+    want = o.generate_batch(prompts, 40, per_row_k=params)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g["generated_tokens"] == w["generated_tokens"]
+        assert (g["proposed"], g["accepted"]) == (w["proposed"], w["accepted"])
+        assert g["k_trace"] == o.k_trace[i]
+    assert len({tuple(g["k_trace"]) for g in got}) > 1
+    # a second run on the same (cached) loop restarts every row's controller
+    again = pipe.generate_batch(prompts, max_tokens=40, do_sample=False)
+    assert [g["k_trace"] for g in again] == [g["k_trace"] for g in got]
+    # and generate() (draft-token emit mode, one row)
+    single = pipe.generate(prompts[1], max_tokens=24, do_sample=False)
+    assert single["generated_tokens"] == OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=tgt.config.eos_token_id).generate(prompts[1], 24)["generated_tokens"]
+
+
+def test_per_row_adaptive_k_with_resyncs_and_admission():
+    """The 'repeating' pair drives the host's de-duplication rules (rows rewound, steps launched ahead voided): the host hands
+    the device its in-order controller state on every repair, so the per-step k still equals the oracle's."""
+    drf, tgt = cases.g8_pairs(torch.bfloat16)["repeating"]
+    params = {"initial_k": 3, "min_k": 1, "max_k": 4, "step_size": 1, "target_acceptance_rate": 0.5}
+    pipe = _pipe(drf, tgt, 4, controller="adaptive", controller_params=dict(params, per_row=True))
+    with open(os.path.join(GOLD, "pipeline_golden.json")) as f:
+        runs = json.load(f)["repeating"]["runs"]
+    prompts = [r["prompt_ids"] for r in runs[:3]]
+    got = pipe.generate_batch(prompts, max_tokens=24, do_sample=False)
+    o = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=2)
+    want = o.generate_batch(prompts, 24, per_row_k=params)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g["generated_tokens"] == w["generated_tokens"]
+        assert (g["proposed"], g["accepted"]) == (w["proposed"], w["accepted"])
+        assert g["k_trace"] == o.k_trace[i]
+    assert got[0]["batch_metrics"]["resyncs"] > 0, "the case no longer exercises the repair path"
+
+
 def test_loud_refusals():
     drf, tgt = tiny_pair()
     pipe = _pipe(drf, tgt, 2)
