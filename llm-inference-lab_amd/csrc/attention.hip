@@ -35,6 +35,8 @@ namespace sd {
 
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attention_mfma_kernel(const AttnArgs a) {
+  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.q), "s"(a.k_cache), "s"(a.v_cache), "s"(a.pos_base), "s"(a.pos_off), "s"(a.M), "s"(a.n_split));
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ns = a.n_split > 1 ? a.n_split : 1;
   attention_tile<D, NW>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);

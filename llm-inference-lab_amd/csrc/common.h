@@ -13,6 +13,25 @@
 
 namespace sd {
 
+// Per-row adaptive K (sd_specdec_set_adaptive): launches of draft forward i >= 1 are in the captured step for every
+// i < K, but when no row proposes more than *k_active tokens the ones with i >= *k_active return at entry (one scalar
+// load; k_active == null, i.e. every other launch, costs a compare). Uniform: every wave takes the same branch.
+// scalar kernel arguments made live at one point (see pin_gemv_args, gemv_device.h): the s_loads are issued back to back
+#ifndef SD_NO_PIN_ARGS
+#define SD_PIN(...) asm volatile("" ::__VA_ARGS__)
+#else
+#define SD_PIN(...)
+#endif
+#ifndef SD_NO_SKIP
+#define SD_SKIP_IF_INACTIVE(kptr, level)                                          \
+  do {                                                                            \
+    if ((kptr) != nullptr && *(kptr) <= (level)) return;                          \
+  } while (0)
+#else
+#define SD_SKIP_IF_INACTIVE(kptr, level) do { } while (0)
+#endif
+
+
 // ---- error plumbing -------------------------------------------------------
 void set_error(const char* fmt, ...);
 void clear_error();

@@ -44,6 +44,8 @@ struct sd_model {
   int max_t = sd::kGemvMaxT; // tokens per pass: 64 when every matrix of the model is covered by gemm_skinny.hip
   int* part_idx = nullptr;
   int head_grid = 0;         // grid of the last lm_head launch (partials per token)
+  const int32_t* skip_k = nullptr;   // set around a draft forward of the adaptive step (enqueue_step): every launch of the
+  int skip_i = 0;                    // forward returns at entry when *skip_k <= skip_i
   std::vector<const void*> packed;  // per matrix (4 per layer + lm_head) or empty: row-major weights
   std::vector<const float*> scales; // fp8 storage: fp32 row scales per matrix
   const void* mat(int index, const void* row_major) const { return packed.empty() ? row_major : packed[index]; }
@@ -94,6 +96,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   e.vocab = c.vocab;
   e.max_pos = c.max_pos;
   e.x = m->x;
+  e.skip_k = m->skip_k;
+  e.skip_i = m->skip_i;
   if (int rc = launch_embed(e, st)) return rc;
 
   const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
@@ -126,6 +130,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     g.l_max = m->Lmax;
     g.out_dtype = SD_BF16;
     g.w8 = m->w8();
+    g.skip_k = m->skip_k;
+    g.skip_i = m->skip_i;
 
     // 1. norm + QKV projection + RoPE + in-place KV append
     g.packed = m->is_packed();
@@ -170,6 +176,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     at.split_ws = m->attn_ws;
     at.split_cnt = m->attn_cnt;
     at.split_slots = kAttnSplitSlots;
+    at.skip_k = m->skip_k;
+    at.skip_i = m->skip_i;
     if (int rc = launch_attention(at, st)) return rc;
 
     // 3. output projection + residual
@@ -257,12 +265,14 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   h.part_idx = m->part_idx;
   h.xstat_in = stat_in;
   h.xstat_n = stat_n;
+  h.skip_k = m->skip_k;
+  h.skip_i = m->skip_i;
   int ks = 1;
   m->head_grid = gemv_grid(h, &ks);
   if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
   if (ids_out) {
     if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, T, m->head_grid, Mc, ids_stride,
-                                        ids_out + static_cast<size_t>(b0) * ids_stride, st))
+                                        ids_out + static_cast<size_t>(b0) * ids_stride, st, m->skip_k, m->skip_i))
       return rc;
   }
   return 0;
@@ -743,8 +753,12 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     const int M = (i == 0) ? 2 : 1;
     const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
     const int off = (i == 0) ? -1 : i;
-    if (int rc = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d))
-      return rc;
+    // per-row adaptive K: forward i >= 1 only matters while some row proposes more than i tokens
+    s->draft->skip_k = (s->st.adaptive && i >= 1) ? s->st.k_active : nullptr;
+    s->draft->skip_i = i;
+    const int rc_f = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+    s->draft->skip_k = nullptr;
+    if (rc_f) return rc_f;
     if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
   }
   if (two) {
@@ -825,7 +839,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * 2 * B * s->rec, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * B * kStageInts, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->host_stage), sizeof(int32_t) * (B * kStageInts + 4), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
     sd_specdec_destroy(s);
@@ -905,7 +919,6 @@ extern "C" int sd_specdec_set_adaptive(sd_specdec* s, int enable, int initial_k,
   s->a_initial = initial_k;
   for (int b = 0; b < s->B; ++b)
     if (int rc = sd_specdec_set_adaptive_row(s, b, initial_k, 0, 0, 1, nullptr, st)) return rc;
-  SD_HIP_CHECK(hipMemsetAsync(s->st.k_active, 0, 4, st));
   return 0;
 }
 
@@ -930,6 +943,10 @@ extern "C" int sd_specdec_set_adaptive_row(sd_specdec* s, int b, int k, int acce
   SD_HIP_CHECK(hipMemcpyAsync(s->st.ctl + 4 * b, h, 16, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.ctl_hist + 4 * b, hd, 32, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.k_row + b, h + 3, 4, hipMemcpyHostToDevice, st));
+  // k_active (which draft forwards run) is recomputed at the end of every step; until then: all of them
+  int32_t* ka = s->host_stage + s->B * kStageInts;
+  *ka = s->st.a_max;
+  SD_HIP_CHECK(hipMemcpyAsync(s->st.k_active, ka, 4, hipMemcpyHostToDevice, st));
   return 0;
 }
 

@@ -62,6 +62,8 @@ static int skinny_chunk(int T, int K, int ksplit, int kw, bool w8 = false) {
 // token group, widened to bf16 in registers as in gemv.hip; the row sum is scaled in the epilogue.
 template <int EPI, int TG, bool W8, int NB>
 __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArgs a, const SkinnyGeom sg) {
+  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   constexpr int KS = W8 ? 64 : 32;   // k per weight step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -413,6 +415,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
 // ------------------------------------------------------------------------------
 template <int EPI, int TG>
 __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArgs a) {
+  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NB = (TG == 1) ? 10 : (TG == 2) ? 6 : (TG == 3) ? 5 : 4;   // steps per batch: NB * (1 + TG) 16-byte loads in flight per lane
   const int K = a.K, T = a.T;
@@ -559,6 +563,8 @@ struct SliceCfg {
 
 template <int EPI, int TG>
 __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs a) {
+  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   using C = SliceCfg<TG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;

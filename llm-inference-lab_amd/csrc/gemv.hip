@@ -142,6 +142,7 @@ template <int EPI, bool MASK, int TT, bool W8, int KB>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   constexpr int kBatch = KB;
   pin_gemv_args<EPI, W8>(a);
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
   const int KP = K + kXPad;

@@ -27,17 +27,13 @@ __device__ __forceinline__ float gelu_new(float x) {
 // asm statement that takes the fields as SGPR INPUT operands makes all of them live at that point: the s_loads are issued
 // back to back (merged into x8 / x16 loads) and waited for once. (Inputs only: as in/out operands the pointers lose
 // their address space, every load becomes a flat_load and the counted vmcnt waits of the prologue are gone.)
-#ifndef SD_NO_PIN_ARGS
-#define SD_PIN(...) asm volatile("" ::__VA_ARGS__)
-#else
-#define SD_PIN(...)
-#endif
+// (SD_PIN: common.h)
 template <int EPI, bool W8>
 __device__ __forceinline__ void pin_gemv_args(const GemvArgs& a) {
   SD_PIN("s"(a.W), "s"(a.K), "s"(a.T), "s"(a.kw), "s"(a.ppw), "s"(a.tile_pairs), "s"(a.ksplit), "s"(a.alias_part),
          "s"(a.debug_ts), "s"(a.packed), "s"(a.n_pairs), "s"(a.x), "s"(a.x_stride), "s"(a.x_row), "s"(a.prologue),
          "s"(a.norm_w), "s"(a.norm_b), "s"(a.norm_eps), "s"(a.out), "s"(a.out_stride), "s"(a.M), "s"(a.bias), "s"(a.N),
-         "s"(a.ks_shift), "s"(a.n_tiles_full), "s"(a.m_magic));
+         "s"(a.ks_shift), "s"(a.n_tiles_full), "s"(a.m_magic), "s"(a.skip_k), "s"(a.skip_i));
   if constexpr (W8) SD_PIN("s"(a.w_scale));
   if constexpr (EPI == EPI_QKV_ROPE)
     SD_PIN("s"(a.head_dim), "s"(a.n_q_heads), "s"(a.n_kv_heads), "s"(a.pos_base), "s"(a.pos_off), "s"(a.rope_cos),

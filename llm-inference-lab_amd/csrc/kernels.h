@@ -71,6 +71,8 @@ struct GemvArgs {
   float* xstat_out;
   const float* xstat_in;
   int xstat_n;
+  const int32_t* skip_k;   // per-row adaptive K: launch of draft forward skip_i returns at entry when *skip_k <= skip_i (null: never)
+  int skip_i;
 };
 constexpr int kStatStride = 256;                    // partials per token (>= workgroups of the producing launch)
 constexpr int kStatPlane = kSkinnyMaxT * kStatStride;   // floats per plane (plane 0: sum of squares, plane 1: sum)
@@ -127,6 +129,8 @@ struct AttnArgs {
   unsigned* split_cnt;
   int split_slots;      // partial tiles the workspace holds
   int n_split;          // set by launch_attention
+  const int32_t* skip_k;   // as GemvArgs
+  int skip_i;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 constexpr int kAttnSplitSlots = 1024;   // partial tiles of the split-KV workspace
@@ -141,11 +145,13 @@ struct EmbedArgs {
   const int32_t* pos_base;
   int pos_off, M, T, d, vocab, max_pos;
   void* x;               // bf16 [T][d]
+  const int32_t* skip_k;   // as GemvArgs
+  int skip_i;
 };
 int launch_embed(const EmbedArgs& a, hipStream_t st);
 
 // reduce the per-workgroup argmax partials: ids[b*ids_stride + m] = argmax over grid
 int launch_argmax_finalize(const float* part_val, const int* part_idx, int T, int grid, int M,
-                           int ids_stride, int32_t* ids_out, hipStream_t st);
+                           int ids_stride, int32_t* ids_out, hipStream_t st, const int32_t* skip_k = nullptr, int skip_i = 0);
 
 }  // namespace sd

@@ -10,6 +10,8 @@ namespace sd {
 // x[t][:] = tok_emb[clamp(token[t])][:] (+ pos_emb[pos][:] for GPT-2)
 // clamp = validate_and_clamp_tokens, /root/reference/src/specdec/utils/token_validation.py:15-78
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.tokens), "s"(a.tok_emb), "s"(a.pos_base), "s"(a.x));
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   const int t = blockIdx.x;
   const int b = t / a.M, m = t - b * a.M;
   int tok = a.tokens[b * a.tok_stride + m];
@@ -61,7 +63,8 @@ __device__ __forceinline__ int fold_partials(const float* pv, const int* pi, int
 // ids[b*ids_stride + m] = argmax over the lm_head partials of token t = b*M + m
 __global__ __launch_bounds__(kWave) void argmax_finalize_kernel(const float* part_val, const int* part_idx,
                                                                 int grid, int M, int ids_stride,
-                                                                int32_t* ids) {
+                                                                int32_t* ids, const int32_t* skip_k, int skip_i) {
+  SD_SKIP_IF_INACTIVE(skip_k, skip_i);
   const int t = blockIdx.x, lane = threadIdx.x;
   const int i = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
   if (lane == 0) {
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(kWave) void argmax_finalize_kernel(const float* par
 }
 
 int launch_argmax_finalize(const float* part_val, const int* part_idx, int T, int grid, int M,
-                           int ids_stride, int32_t* ids_out, hipStream_t st) {
+                           int ids_stride, int32_t* ids_out, hipStream_t st, const int32_t* skip_k, int skip_i) {
   hipLaunchKernelGGL(argmax_finalize_kernel, dim3(T), dim3(kWave), 0, st, part_val, part_idx, grid, M,
-                     ids_stride, ids_out);
+                     ids_stride, ids_out, skip_k, skip_i);
   SD_LAUNCH_CHECK();
   return 0;
 }
@@ -81,6 +84,7 @@ int launch_argmax_finalize(const float* part_val, const int* part_idx, int T, in
 // ---- draft: token i of the proposal ------------------------------------------------
 // The draft forward produced M tokens per row; the last one's argmax is d_{i+1}.
 __global__ void draft_next_kernel(int M, int i, SpecState s) {
+  if (s.adaptive && i >= 1) SD_SKIP_IF_INACTIVE(s.k_active, i);   // forward i did not run: d_{i+1} counts for no row
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= s.B) return;
   const int d = s.draft_ids[b * 2 + (M - 1)];
