@@ -347,9 +347,13 @@ int sd_specdec_reset_eagle(sd_specdec* s, void* stream);
 /* Persistent multi-head (Medusa) drafting for a loop created with draft = NULL: K heads, each a
  * vocabulary-sized matrix [V][d_model] packed by sd_pack_head in `weight_dtype`. After the accept scan of a step
  * the heads read the target's final-norm input row of the position that produced the last emitted token and
- * propose d_{i+1} = argmax head_i(norm(h)) for the NEXT step: one lm_head-shaped GEMV per head, no draft forwards.
+ * propose d_{i+1} = argmax head_i(norm(h)) for the NEXT step, no draft forwards. Heads that sit at a CONSTANT byte
+ * stride (packed_heads[i+1] - packed_heads[i] equal for all i, e.g. one buffer of K slots) are evaluated by ONE launch
+ * (one matrix per grid row over the same hidden rows) + one argmax finalize; otherwise one launch per head. Up to 9
+ * rows read the hidden rows in place; more (within one verify pass: B*(K+1) <= 64) are gathered first and take the
+ * multi-token kernel, one launch per head.
  * (Not in the reference: its Medusa mode re-creates random heads per call, pipeline.py:689-705)
- * Requires B <= 9 and B*(K+1) within one verify pass. Drops the captured graph. */
+ * Requires B*(K+1) within one verify pass. Drops the captured graph. */
 int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* const* packed_heads, int weight_dtype);
 
 /* Enqueue ONE draft-then-verify step for all rows: K draft forwards (the first over

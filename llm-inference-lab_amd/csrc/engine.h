@@ -38,6 +38,7 @@ int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);
 int launch_medusa_fill(const SpecState& s, hipStream_t st);
 int launch_medusa_rows(const SpecState& s, int32_t* row_idx, hipStream_t st);
 int launch_medusa_commit(const SpecState& s, hipStream_t st);
+int launch_medusa_gather(const void* x, const int32_t* rows, void* out, int B, int d, hipStream_t st);
 int launch_eagle_extrapolate(const void* x, void* H, void* prev, int32_t* has_prev, const void* norm_w, const void* norm_b,
                              float eps, float alpha, int d, int B, int K, int rms, hipStream_t st);
 int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st);

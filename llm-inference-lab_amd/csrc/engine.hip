@@ -626,6 +626,7 @@ struct sd_specdec {
   std::vector<const void*> heads;
   std::vector<const float*> head_scales;
   int32_t* head_rows = nullptr;    // [B] device: row of the target's residual stream each head reads
+  size_t head_stride = 0;          // bytes between consecutive heads when they sit at a constant stride (one launch), else 0
   // EAGLE-lite (sd_specdec_set_eagle): extrapolated hidden rows instead of a draft model; caller-owned workspace
   int eagle = 0;
   float eagle_alpha = 0.7f;
@@ -668,36 +669,53 @@ __global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t
 }
 
 // draft tokens of the NEXT step from the heads: d_{i+1} = argmax head_i(final_norm(h)), h = the residual row of the
-// position that produced the last emitted token. One lm_head-shaped GEMV + finalize per head.
+// position that produced the last emitted token. Heads the caller packed at a constant stride (sd_specdec_set_medusa)
+// are evaluated by ONE lm_head-shaped launch (grid y = head: same x rows, same geometry, per-head argmax partials) and
+// one finalize over K x B results; otherwise one launch + finalize per head.
 static int enqueue_medusa_heads(sd_specdec* s, hipStream_t st) {
   sd_model* m = s->target;
   const sd_model_config& c = m->cfg;
   const int B = s->B, K = s->K;
   if (int rc = launch_medusa_rows(s->st, s->head_rows, st)) return rc;
+  GemvArgs h{};
+  h.packed = 1;
+  h.w8 = s->head_scales.empty() ? 0 : 1;
+  h.N = c.vocab;
+  h.K = c.d_model;
+  h.n_pairs = (c.vocab + 1) / 2;
+  h.x = m->x;
+  h.x_stride = c.d_model;
+  h.x_row = s->head_rows;
+  h.T = B;
+  h.M = 1;
+  h.prologue = (c.arch == SD_ARCH_LLAMA) ? PRO_RMSNORM : PRO_LAYERNORM;
+  h.norm_w = c.final_norm_w;
+  h.norm_b = c.final_norm_b;
+  h.norm_eps = c.norm_eps;
+  h.out = nullptr;
+  h.out_dtype = SD_BF16;
+  h.part_val = m->part_val;
+  h.part_idx = m->part_idx;
+  if (B > m->small_t) {   // more rows than a GEMV pass: gather them (the attention-output buffer is free after the verify forward)
+    if (int rc = launch_medusa_gather(m->x, s->head_rows, m->attn, B, c.d_model, st)) return rc;
+    h.x = m->attn;
+    h.x_row = nullptr;
+  }
+  int ppw = 1;
+  const int grid = gemv_grid(h, &ppw);
+  if (B <= m->small_t && s->head_stride && static_cast<size_t>(K) * B * grid <= static_cast<size_t>(kSkinnyMaxT) * kMaxPartials) {
+    h.W = s->heads[0];
+    h.w_scale = s->head_scales.empty() ? nullptr : s->head_scales[0];
+    h.batch_bytes = s->head_stride;
+    h.n_batch = K;
+    if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
+    // result (head j, row b) = "token" j * B + b of the partials -> verify_tok[b][j + 1]
+    if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, K * B, grid, -B, K + 1, s->st.verify_tok + 1, st)) return rc;
+    return launch_medusa_commit(s->st, st);
+  }
   for (int i = 0; i < K; ++i) {
-    GemvArgs h{};
-    h.packed = 1;
-    h.w8 = s->head_scales.empty() ? 0 : 1;
     h.w_scale = s->head_scales.empty() ? nullptr : s->head_scales[i];
     h.W = s->heads[i];
-    h.N = c.vocab;
-    h.K = c.d_model;
-    h.n_pairs = (c.vocab + 1) / 2;
-    h.x = m->x;
-    h.x_stride = c.d_model;
-    h.x_row = s->head_rows;
-    h.T = B;
-    h.M = 1;
-    h.prologue = (c.arch == SD_ARCH_LLAMA) ? PRO_RMSNORM : PRO_LAYERNORM;
-    h.norm_w = c.final_norm_w;
-    h.norm_b = c.final_norm_b;
-    h.norm_eps = c.norm_eps;
-    h.out = nullptr;
-    h.out_dtype = SD_BF16;
-    h.part_val = m->part_val;
-    h.part_idx = m->part_idx;
-    int ppw = 1;
-    const int grid = gemv_grid(h, &ppw);
     if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
     // token of head i of row b -> verify_tok[b][i+1]
     if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, B, grid, 1, K + 1, s->st.verify_tok + i + 1, st)) return rc;
@@ -1023,7 +1041,8 @@ extern "C" int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* con
   SD_REQUIRE(n_heads == s->K && packed_heads, "specdec_set_medusa: need K = %d heads, got %d", s->K, n_heads);
   SD_REQUIRE(weight_dtype == SD_BF16 || weight_dtype == SD_FP8_E4M3, "specdec_set_medusa: weight_dtype %d", weight_dtype);
   const sd_model_config& c = s->target->cfg;
-  SD_REQUIRE(s->B <= gemv_max_tokens(c.d_model), "specdec_set_medusa: batch %d exceeds one GEMV pass (%d rows)", s->B, gemv_max_tokens(c.d_model));
+  SD_REQUIRE(s->B <= s->target->small_t || (s->B <= s->target->max_t && c.n_heads * c.head_dim >= c.d_model),
+             "specdec_set_medusa: batch %d exceeds one pass of the head kernels (%d rows)", s->B, s->target->max_t);
   SD_REQUIRE(s->B * (s->K + 1) <= s->target->max_t, "specdec_set_medusa: the verify pass must be a single pass (B*(K+1) = %d > %d)",
              s->B * (s->K + 1), s->target->max_t);
   if (s->exec) {
@@ -1042,6 +1061,15 @@ extern "C" int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* con
                          ((static_cast<size_t>((c.vocab + 1) / 2) * 2 * 4 + 255) & ~static_cast<size_t>(255));
       s->head_scales.push_back(reinterpret_cast<const float*>(static_cast<const char*>(packed_heads[i]) + off));
     }
+  }
+  s->head_stride = 0;
+  if (n_heads >= 2 && !getenv("SPECDEC_MEDUSA_PER_HEAD")) {
+    const char* h0 = static_cast<const char*>(packed_heads[0]);
+    const char* h1 = static_cast<const char*>(packed_heads[1]);
+    bool even = h1 > h0;
+    for (int i = 2; even && i < n_heads; ++i)
+      even = static_cast<const char*>(packed_heads[i]) - static_cast<const char*>(packed_heads[i - 1]) == h1 - h0;
+    if (even) s->head_stride = static_cast<size_t>(h1 - h0);
   }
   if (!s->head_rows) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->head_rows), sizeof(int32_t) * s->B));
   return 0;

@@ -165,6 +165,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
   const int k_begin = kpart * kw;
   const int steps = W8 ? (kw >> 6) : (kw >> 5);  // loads per slice (an fp8 load covers 64 k)
   const uint16_t* W = static_cast<const uint16_t*>(a.W);
+  const float* wsc = a.w_scale;
+  size_t part_off = 0;
+  if constexpr (EPI == EPI_ARGMAX) {
+    if (a.batch_bytes) {   // Medusa heads: matrix blockIdx.y of n_batch, same geometry, same x rows
+      W = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(W) + blockIdx.y * a.batch_bytes);
+      if constexpr (W8) wsc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wsc) + blockIdx.y * a.batch_bytes);
+      part_off = static_cast<size_t>(blockIdx.y) * T * gridDim.x;
+    }
+  }
 
   // contiguous pair range of this workgroup, cut into n_tiles tiles of tile_pairs pairs
   const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
         int r0, r1;
         pair_rows<EPI>(a, p, r0, r1);
         if constexpr (W8) {
-          y0 *= a.w_scale[r0];
-          y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;
+          y0 *= wsc[r0];
+          y1 *= (r1 < a.N) ? wsc[r1] : 0.f;
         }
         epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v, best_i, have_old && r == 0 && it == tid, old_pre);
       }
@@ -452,8 +461,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       int bi = si[wave * 64 + lane];
       wave_reduce_argmax(bv, bi);
       if (lane == 0) {
-        a.part_val[static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bv;
-        a.part_idx[static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bi;
+        a.part_val[part_off + static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bv;
+        a.part_idx[part_off + static_cast<size_t>(wave) * gridDim.x + blockIdx.x] = bi;
       }
     }
   }
@@ -492,7 +501,7 @@ static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8, KB>), dim3(grid), dim3(kGemvThreads), smem, st, a);
+  hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8, KB>), dim3(grid, a.batch_bytes ? a.n_batch : 1), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
@@ -519,11 +528,15 @@ static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipSt
 }
 
 int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
-  if (a_in.T > kGemvMaxT) return launch_gemm_skinny(a_in, epi, st);
+  if (a_in.T > kGemvMaxT) {
+    SD_REQUIRE(!a_in.batch_bytes, "gemv: batched matrices need T <= %d", kGemvMaxT);
+    return launch_gemm_skinny(a_in, epi, st);
+  }
   GemvArgs a = a_in;
   SD_REQUIRE(a.T >= 1 && a.T <= kGemvMaxT, "gemv: T=%d out of range 1..%d", a.T, kGemvMaxT);
   SD_REQUIRE(a.K % 8 == 0 && a.x_stride % 8 == 0, "gemv: K=%d / x_stride=%d must be multiples of 8", a.K, a.x_stride);
   SD_REQUIRE(a.n_pairs > 0, "gemv: no rows");
+  SD_REQUIRE(!a.batch_bytes || (epi == EPI_ARGMAX && a.n_batch >= 1 && a.n_batch <= 64 && !a.out), "gemv: batched matrices are an ARGMAX-epilogue feature (no logits store)");
   // one workgroup (16 waves) per CU with an equal, contiguous share of the row pairs, cut into
   // a power-of-two count of <= 8-pair tiles; the 16 waves take (tile, K-slice) units
   const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
@@ -549,7 +562,7 @@ int launch_gemv(const GemvArgs& a_in, int epi, hipStream_t st) {
   }
   // rows too long to stage T of them whole (d_ff = 14336 takes 5): the chunked multi-token kernel covers the rest
   // of 6..9 tokens — a pass may mix both kernels, they share layout, work split and epilogues
-  if (smem > kLdsLimit && !a.x_row && gemm_skinny_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return launch_gemm_skinny(a_in, epi, st);
+  if (smem > kLdsLimit && !a.x_row && !a.batch_bytes && gemm_skinny_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return launch_gemm_skinny(a_in, epi, st);
   SD_REQUIRE(smem <= kLdsLimit, "gemv: T=%d x K=%d does not fit LDS", a.T, a.K);
   switch (epi) {
     case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(a, mask, grid, smem, st);

@@ -71,6 +71,10 @@ struct GemvArgs {
   float* xstat_out;
   const float* xstat_in;
   int xstat_n;
+  // EPI_ARGMAX, gemv.hip only: n_batch equally shaped matrices at a constant byte stride (the K Medusa heads), one per
+  // blockIdx.y, over the SAME x rows; partials of matrix j at part_val/part_idx + j * T * grid. 0 = a single matrix.
+  size_t batch_bytes;
+  int n_batch;
   const int32_t* skip_k;   // per-row adaptive K: launch of draft forward skip_i returns at entry when *skip_k <= skip_i (null: never)
   int skip_i;
 };

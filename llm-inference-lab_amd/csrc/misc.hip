@@ -68,8 +68,14 @@ __global__ __launch_bounds__(kWave) void argmax_finalize_kernel(const float* par
   const int t = blockIdx.x, lane = threadIdx.x;
   const int i = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
   if (lane == 0) {
-    const int b = t / M, m = t - b * M;
-    ids[b * ids_stride + m] = i;
+    // M > 0: token t = b * M + m. M < 0 (the batched head launch): t = j * B + b with B = -M rows per matrix j -> ids[b][j]
+    if (M > 0) {
+      const int b = t / M, m = t - b * M;
+      ids[b * ids_stride + m] = i;
+    } else {
+      const int j = t / -M, b = t + j * M;
+      ids[b * ids_stride + j] = i;
+    }
   }
 }
 
@@ -112,6 +118,21 @@ __global__ void medusa_fill_kernel(SpecState s) {
 __global__ void medusa_rows_kernel(SpecState s, int32_t* row_idx) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < s.B) row_idx[b] = b * (s.K + 1) + s.accept_len[b];
+}
+
+// more rows than one GEMV pass takes (> 9): the rows the heads read, gathered into a contiguous block for the
+// multi-token kernels (which have no row indirection)
+__global__ __launch_bounds__(256) void medusa_gather_kernel(const uint16_t* x, const int32_t* rows, uint16_t* out, int d) {
+  const uint4* src = reinterpret_cast<const uint4*>(x + static_cast<size_t>(rows[blockIdx.x]) * d);
+  uint4* dst = reinterpret_cast<uint4*>(out + static_cast<size_t>(blockIdx.x) * d);
+  for (int i = threadIdx.x; i < d / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+int launch_medusa_gather(const void* x, const int32_t* rows, void* out, int B, int d, hipStream_t st) {
+  SD_REQUIRE(d % 8 == 0, "medusa_gather: d=%d", d);
+  hipLaunchKernelGGL(medusa_gather_kernel, dim3(B), dim3(256), 0, st, static_cast<const uint16_t*>(x), rows, static_cast<uint16_t*>(out), d);
+  SD_LAUNCH_CHECK();
+  return 0;
 }
 
 __global__ void medusa_commit_kernel(SpecState s) {

@@ -261,15 +261,15 @@ class HipSpecDec:
             raise ValueError(f"medusa heads must be bf16 [{self.K}][V][d] on {self.device}")
         wd = _abi.SD_FP8_E4M3 if weight_dtype == "fp8" else _abi.SD_BF16
         nbytes = self.lib.sd_packed_head_bytes(V, d, wd)
-        self._heads_packed = []
+        stride = (nbytes + 255) // 256 * 256      # heads at a constant stride in ONE buffer: the engine evaluates them in one launch
         with torch.cuda.device(self.device):
             st = torch.cuda.current_stream(self.device)
+            self._heads_packed = torch.empty(K * stride, dtype=torch.uint8, device=self.device)
+            base = self._heads_packed.data_ptr()
             for i in range(K):
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-                _abi.check(self.lib.sd_pack_head(heads[i].contiguous().data_ptr(), V, d, wd, buf.data_ptr(), nbytes, st.cuda_stream), "sd_pack_head")
-                self._heads_packed.append(buf)
+                _abi.check(self.lib.sd_pack_head(heads[i].contiguous().data_ptr(), V, d, wd, base + i * stride, nbytes, st.cuda_stream), "sd_pack_head")
             st.synchronize()
-            arr = (ctypes.c_void_p * K)(*[b.data_ptr() for b in self._heads_packed])
+            arr = (ctypes.c_void_p * K)(*[base + i * stride for i in range(K)])
             _abi.check(self.lib.sd_specdec_set_medusa(self.handle, K, arr, wd), "sd_specdec_set_medusa")
 
     def set_eagle(self, alpha: float = 0.7, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -367,8 +367,9 @@ def test_generate_many_continuous_batching():
     assert [r["generated_tokens"] for r in s1] == [r["generated_tokens"] for r in s2]
 
 
-@pytest.mark.parametrize("k,batch,wd", [(4, 1, "bf16"), (2, 3, "bf16"), (4, 2, "fp8")])
-def test_persistent_medusa_heads(k, batch, wd):
+@pytest.mark.parametrize("k,batch,wd,per_head", [(4, 1, "bf16", False), (2, 3, "bf16", False), (4, 2, "fp8", False),
+                                                 (4, 2, "bf16", True), (3, 9, "fp8", False), (4, 11, "bf16", False)])
+def test_persistent_medusa_heads(k, batch, wd, per_head, monkeypatch):
     """K persistent heads over the target's last hidden state replace the draft forwards (not in the reference,
     SURVEY §8 f4): tokens, proposed/accepted counters and steps equal the oracle restatement; the output is the
     target's greedy continuation; with 20 % wrong head rows the acceptance is high but not total."""
@@ -376,6 +377,10 @@ def test_persistent_medusa_heads(k, batch, wd):
     from specdec_hip import weights as W
     from src.specdec import HipLM, SpeculativePipeline
 
+    # the K heads are ONE launch (grid row = head) up to 9 rows; per_head forces the one-launch-per-head path, 11 rows take
+    # the gathered multi-token path
+    if per_head:
+        monkeypatch.setenv("SPECDEC_MEDUSA_PER_HEAD", "1")
     drf, tgt = tiny_pair()
     heads = W.synthetic_medusa_heads(tgt, k, flip_fraction=0.2)
     V = tgt.config.vocab
