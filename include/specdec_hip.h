@@ -243,6 +243,21 @@ size_t sd_model_kv_bytes(const sd_model* m, int B, int Lmax);
 int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax,
                   void* workspace, size_t workspace_bytes);
 
+/* Paged KV (the counterpart of the reference's per-sequence cache tensors that grow by torch.cat
+ * and are realigned to a common length, src/specdec/cache/kv_cache_manager.py:194-199 and :353-479): instead of Lmax
+ * positions per row, rows own PAGES of page_len positions (a power of two >= 32) out of pools shared by all rows:
+ *   K pool: [n_layers][n_pages][Hkv][page_len][D]    V pool: [n_layers][n_pages][Hkv][D][page_len]   (bf16)
+ * and position pos of row b lives in page block_table[b * max_pages_per_row + pos / page_len] (the same page index in
+ * every layer) at offset pos % page_len. `block_table` is device memory, caller-owned and caller-maintained: an entry
+ * must be valid before a forward reads or writes a position in it (write entries on the stream the forward runs on, or
+ * synchronise); entries of positions a row has not reached are never read. The row's capacity is
+ * max_pages_per_row * page_len. Everything else (forward, step loop, C-ABI) is unchanged; sd_model_probe_gemv's QKV
+ * probe is not available on a paged model. */
+size_t sd_model_kv_pool_bytes(const sd_model* m, int n_pages, int page_len);   /* ONE of the two pools */
+int sd_model_bind_paged(sd_model* m, void* k_pool, void* v_pool, int n_pages, int page_len,
+                        const int32_t* block_table, int max_pages_per_row, int B,
+                        void* workspace, size_t workspace_bytes);
+
 /* One forward over M new tokens per batch row, appended to the KV cache in place.
  *   tokens   : device int32, token (b,m) at tokens[b*tok_stride + m]
  *   pos_base : device int32[B]; token (b,m) sits at position pos_base[b] + pos_off + m

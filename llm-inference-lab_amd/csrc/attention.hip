@@ -33,25 +33,29 @@
 
 namespace sd {
 
-template <int D, int NW>
+template <int D, int NW, bool PAGED>
 __global__ __launch_bounds__(NW * 64) void attention_mfma_kernel(const AttnArgs a) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.q), "s"(a.k_cache), "s"(a.v_cache), "s"(a.pos_base), "s"(a.pos_off), "s"(a.M), "s"(a.n_split));
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ns = a.n_split > 1 ? a.n_split : 1;
-  attention_tile<D, NW>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);
+  attention_tile<D, NW, PAGED>(a, blockIdx.x, blockIdx.y, blockIdx.z / ns, smem, true, blockIdx.z % ns);
+}
+
+template <int D, int NW, bool PAGED>
+static void launch_attention_one_p(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t smem = attention_smem_bytes(D, NW);
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<D, NW, PAGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_mfma_kernel<D, NW, PAGED>), grid, dim3(NW * 64), smem, st, a);
 }
 
 template <int D, int NW>
 static void launch_attention_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
-  const size_t smem = attention_smem_bytes(D, NW);
-  if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(smem));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((attention_mfma_kernel<D, NW>), grid, dim3(NW * 64), smem, st, a);
+  if (a.block_table) launch_attention_one_p<D, NW, true>(a, grid, st);
+  else launch_attention_one_p<D, NW, false>(a, grid, st);
 }
 
 template <int D>
@@ -77,6 +81,8 @@ int launch_attention(const AttnArgs& a_in, hipStream_t st) {
   SD_REQUIRE(a.n_kv_heads > 0 && a.n_q_heads % a.n_kv_heads == 0, "attention: Hq %% Hkv != 0");
   SD_REQUIRE(a.B >= 1 && a.M >= 1, "attention: empty batch");
   SD_REQUIRE(a.l_max % 8 == 0 && a.l_max >= 8, "attention: l_max=%d must be a multiple of 8", a.l_max);
+  SD_REQUIRE(!a.block_table || (a.page_shift >= 5 && a.page_shift <= 16 && a.max_pages >= 1 && a.l_max == (a.max_pages << a.page_shift)),
+             "attention: paged cache needs pages of 32 * 2^n positions and l_max = max_pages * page_len");
   const int G = a.n_q_heads / a.n_kv_heads;
   const int R = G * a.M;
   const int tiles = (R + kAttnRows - 1) / kAttnRows;

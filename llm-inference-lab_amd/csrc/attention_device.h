@@ -37,7 +37,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // keys), the others leave at once. Each computes an un-normalised partial over its blocks; the last to
 // arrive (device-scope counter) merges them — flash-decoding across CUs, for contexts where one
 // workgroup per kv head would walk thousands of keys while 248 CUs idle.
-template <int D, int NW>
+// PAGED (sd_model_bind_paged): the caches are page pools; a 32-key block never straddles a page (P is a multiple of 32),
+// so each block costs one wave-uniform table read and the V^T row stride is P instead of l_max.
+template <int D, int NW, bool PAGED = false>
 __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b, int tile, unsigned char* smem,
                                                bool active, int split = 0) {
   constexpr int kAttnWaves = NW, kAttnThreads = NW * 64;
@@ -54,6 +56,9 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
   float* m_s = o_s + kAttnWaves * kAttnRows * D;          // [waves][16]
   float* l_s = m_s + kAttnWaves * kAttnRows;              // [waves][16]
 
+  // per-row adaptive K: a launch of a draft forward no row needs leaves here (the arguments are first needed here, so
+  // the check adds no wait of its own; workgroup-uniform, before any barrier)
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   const int pos0 = a.pos_base[b] + a.pos_off;             // position of query m = 0
   const int n_keys = max(0, min(pos0 + M, a.l_max));      // keys visible to the last query
   const int n_blocks = (n_keys + kAttnBlock - 1) / kAttnBlock;
@@ -83,6 +88,8 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
 
   const uint16_t* kc = static_cast<const uint16_t*>(a.k_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max * D;
   const uint16_t* vt = static_cast<const uint16_t*>(a.v_cache) + (static_cast<size_t>(b) * a.n_kv_heads + kvh) * D * a.l_max;
+  (void)kc; (void)vt;
+  const int vstride = PAGED ? (1 << a.page_shift) : a.l_max;   // positions per V^T row
 
   f32x4_t oacc[NDT];
 #pragma unroll
@@ -93,13 +100,20 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
 
   for (int blk = active ? split * kAttnWaves + wave : n_blocks; blk < n_blocks; blk += kAttnWaves * s_eff) {
     const int key0 = blk * kAttnBlock;
+    int kbase = key0;                       // position of the block's first key inside its slab
+    if constexpr (PAGED) {
+      const int pg = __builtin_amdgcn_readfirstlane(a.block_table[b * a.max_pages + (key0 >> a.page_shift)]);
+      kc = static_cast<const uint16_t*>(a.k_cache) + ((static_cast<size_t>(pg) * a.n_kv_heads + kvh) << a.page_shift) * D;
+      vt = static_cast<const uint16_t*>(a.v_cache) + ((static_cast<size_t>(pg) * a.n_kv_heads + kvh) * D << a.page_shift);
+      kbase = key0 & (vstride - 1);
+    }
     // ---- issue every load of the block -------------------------------------------
     // S^T tile u (u = 0,1): MFMA row i (= lane n) is key  key0 + 8*(i>>2) + 4*u + (i&3)
     u32x4 kf[2][NKS];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      int key = key0 + 8 * (n >> 2) + 4 * u + (n & 3);
-      if (key >= a.l_max) key = a.l_max - 1;  // stay inside the cache; masked below
+      int key = kbase + 8 * (n >> 2) + 4 * u + (n & 3);
+      if (!PAGED && key >= a.l_max) key = a.l_max - 1;  // stay inside the cache; masked below (a page holds the whole block)
       const uint16_t* krow = kc + static_cast<size_t>(key) * D + g * 8;
 #pragma unroll
       for (int s = 0; s < NKS; ++s) kf[u][s] = *reinterpret_cast<const u32x4*>(krow + s * 32);
@@ -107,11 +121,11 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
     // V^T fragment of channel tile i: lane (g, n) holds V^T[16 i + n][key0 + 8 g .. +8]
     u32x4 vf[NDT];
     {
-      int kofs = key0 + 8 * g;
-      if (kofs + 8 > a.l_max) kofs = a.l_max - 8;  // l_max % 8 == 0 (checked by the host)
-      const uint16_t* vrow = vt + static_cast<size_t>(n) * a.l_max + kofs;
+      int kofs = kbase + 8 * g;
+      if (!PAGED && kofs + 8 > a.l_max) kofs = a.l_max - 8;  // l_max % 8 == 0 (checked by the host)
+      const uint16_t* vrow = vt + static_cast<size_t>(n) * vstride + kofs;
 #pragma unroll
-      for (int i = 0; i < NDT; ++i) vf[i] = *reinterpret_cast<const u32x4*>(vrow + static_cast<size_t>(16 * i) * a.l_max);
+      for (int i = 0; i < NDT; ++i) vf[i] = *reinterpret_cast<const u32x4*>(vrow + static_cast<size_t>(16 * i) * vstride);
     }
     // ---- S^T = K Q^T -----------------------------------------------------------------
     f32x4_t st[2];

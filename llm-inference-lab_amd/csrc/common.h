@@ -23,10 +23,34 @@ namespace sd {
 #define SD_PIN(...)
 #endif
 #ifndef SD_NO_SKIP
+#if defined(SD_SKIP_BRANCH)
 #define SD_SKIP_IF_INACTIVE(kptr, level)                                          \
   do {                                                                            \
     if ((kptr) != nullptr && *(kptr) <= (level)) return;                          \
   } while (0)
+#else
+// As ONE opaque statement (scalar compare, conditional scalar load, s_endpgm): written as C++ (`if (...) return;`) the
+// early exit splits the kernel's entry block, and everything the scheduler used to place under the latency of the
+// argument loads (lane / tile index arithmetic) then waits behind the branch — 0.5 % of the batch-1 step with the
+// check compiled in and never taken. Every wave of the launch takes the same path; nothing is in flight that matters
+// (the hardware drains a wave's outstanding loads at s_endpgm).
+#define SD_SKIP_IF_INACTIVE(kptr, level)                                          \
+  do {                                                                            \
+    int sd_skip_tmp_;                                                             \
+    asm volatile(                                                                 \
+        "s_cmp_eq_u64 %1, 0\n\t"                                                  \
+        "s_cbranch_scc1 1f\n\t"                                                   \
+        "s_load_dword %0, %1, 0x0\n\t"                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                \
+        "s_cmp_gt_i32 %0, %2\n\t"                                                 \
+        "s_cbranch_scc1 1f\n\t"                                                   \
+        "s_endpgm\n"                                                              \
+        "1:"                                                                      \
+        : "=&s"(sd_skip_tmp_)                                                     \
+        : "s"(kptr), "s"(level)                                                   \
+        : "scc");                                                                 \
+  } while (0)
+#endif
 #else
 #define SD_SKIP_IF_INACTIVE(kptr, level) do { } while (0)
 #endif

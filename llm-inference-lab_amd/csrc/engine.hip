@@ -30,6 +30,9 @@ struct sd_model {
   uint16_t* k_cache = nullptr;
   uint16_t* v_cache = nullptr;
   int B = 0, Lmax = 0;
+  // paged KV (sd_model_bind_paged): k_cache / v_cache are page pools of n_pages pages per layer, Lmax = max_pages * page_len
+  const int32_t* block_table = nullptr;   // device [B][max_pages], caller-owned and caller-maintained
+  int page_shift = 0, max_pages = 0, n_pages = 0;
   // workspace carve
   uint16_t* x = nullptr;     // [64][d]
   uint16_t* q = nullptr;     // [64][Hq*D]
@@ -100,7 +103,10 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   e.skip_i = m->skip_i;
   if (int rc = launch_embed(e, st)) return rc;
 
-  const size_t layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+  const bool paged = m->block_table != nullptr;
+  const size_t layer_kv = paged ? (static_cast<size_t>(m->n_pages) * Hkv * D << m->page_shift) : static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+  const size_t row_kv = paged ? 0 : static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;    // paged: rows are found through the table
+  const int32_t* bt = paged ? m->block_table + static_cast<size_t>(row0 + b0) * m->max_pages : nullptr;
   // > 9 tokens: the launch that writes the residual stream hands its row statistics to the launch that normalises it
   const float* stat_in = nullptr;
   int stat_n = 0;
@@ -115,8 +121,8 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   };
   for (int l = 0; l < c.n_layers; ++l) {
     const sd_layer_weights& w = m->layers[l];
-    uint16_t* kc = m->k_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
-    uint16_t* vc = m->v_cache + l * layer_kv + static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
+    uint16_t* kc = m->k_cache + l * layer_kv + row_kv;
+    uint16_t* vc = m->v_cache + l * layer_kv + row_kv;
 
     GemvArgs g{};
     g.T = T;
@@ -130,6 +136,9 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     g.l_max = m->Lmax;
     g.out_dtype = SD_BF16;
     g.w8 = m->w8();
+    g.block_table = bt;
+    g.page_shift = m->page_shift;
+    g.max_pages = m->max_pages;
     g.skip_k = m->skip_k;
     g.skip_i = m->skip_i;
 
@@ -176,6 +185,9 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     at.split_ws = m->attn_ws;
     at.split_cnt = m->attn_cnt;
     at.split_slots = kAttnSplitSlots;
+    at.block_table = bt;
+    at.page_shift = m->page_shift;
+    at.max_pages = m->max_pages;
     at.skip_k = m->skip_k;
     at.skip_i = m->skip_i;
     if (int rc = launch_attention(at, st)) return rc;
@@ -413,6 +425,8 @@ extern "C" size_t sd_model_kv_bytes(const sd_model* m, int B, int Lmax) {
   return static_cast<size_t>(m->cfg.n_layers) * B * m->cfg.n_kv_heads * Lmax * m->cfg.head_dim * 2;
 }
 
+static int carve_workspace(sd_model* m, void* workspace);
+
 extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, int Lmax, void* workspace,
                              size_t workspace_bytes_) {
   clear_error();
@@ -425,6 +439,42 @@ extern "C" int sd_model_bind(sd_model* m, void* k_cache, void* v_cache, int B, i
   m->v_cache = static_cast<uint16_t*>(v_cache);
   m->B = B;
   m->Lmax = Lmax;
+  m->block_table = nullptr;
+  m->page_shift = m->max_pages = m->n_pages = 0;
+  return carve_workspace(m, workspace);
+}
+
+extern "C" size_t sd_model_kv_pool_bytes(const sd_model* m, int n_pages, int page_len) {
+  if (!m || n_pages <= 0 || page_len <= 0) return 0;
+  return static_cast<size_t>(m->cfg.n_layers) * n_pages * m->cfg.n_kv_heads * page_len * m->cfg.head_dim * 2;
+}
+
+// Paged KV: rows do not own Lmax positions each; they own pages of page_len positions out of a pool shared by all
+// rows, through a caller-maintained table (the counterpart of the reference's cache manager growing / realigning
+// per-sequence tensors, kv_cache_manager.py:194-199, :353-479 — here a row grows by a table entry).
+extern "C" int sd_model_bind_paged(sd_model* m, void* k_pool, void* v_pool, int n_pages, int page_len, const int32_t* block_table,
+                                   int max_pages_per_row, int B, void* workspace, size_t workspace_bytes_) {
+  clear_error();
+  SD_REQUIRE(m && k_pool && v_pool && block_table && workspace, "model_bind_paged: NULL argument");
+  SD_REQUIRE(B >= 1 && n_pages >= 1 && max_pages_per_row >= 1, "model_bind_paged: B=%d pages=%d max_pages=%d", B, n_pages, max_pages_per_row);
+  int shift = 0;
+  while ((1 << shift) < page_len) ++shift;
+  SD_REQUIRE((1 << shift) == page_len && page_len >= 32 && page_len <= 65536, "model_bind_paged: page_len %d must be a power of two >= 32", page_len);
+  SD_REQUIRE(workspace_bytes_ >= workspace_bytes(m->cfg), "model_bind_paged: workspace too small");
+  SD_REQUIRE((reinterpret_cast<uintptr_t>(k_pool) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_pool) & 15) == 0,
+             "model_bind_paged: pools must be 16-byte aligned");
+  m->k_cache = static_cast<uint16_t*>(k_pool);
+  m->v_cache = static_cast<uint16_t*>(v_pool);
+  m->B = B;
+  m->Lmax = max_pages_per_row * page_len;
+  m->block_table = block_table;
+  m->page_shift = shift;
+  m->max_pages = max_pages_per_row;
+  m->n_pages = n_pages;
+  return carve_workspace(m, workspace);
+}
+
+static int carve_workspace(sd_model* m, void* workspace) {
   const sd_model_config& c = m->cfg;
   const size_t T = kSkinnyMaxT;
   char* p = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
@@ -511,6 +561,7 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
     if (use_xstat && (which == 0 || which == 2 || which == 4)) { g.xstat_in = m->xstat; g.xstat_n = 256; }
     switch (which) {
       case 0: {  // norm + QKV projection + RoPE + in-place KV append (row 0 of the cache, positions 0..T-1)
+        SD_REQUIRE(!m->block_table, "probe_gemv: the QKV probe writes dense cache rows (not available on a paged model)");
         const int Hkv = c.n_kv_heads;
         g.W = m->mat(4 * li + 0, w.wqkv); g.bias = w.bqkv; g.N = (Hq + 2 * Hkv) * D; g.K = d; g.n_pairs = g.N / 2;
         g.x = m->x; g.x_stride = d; g.prologue = llama ? PRO_RMSNORM : PRO_LAYERNORM; g.norm_w = w.attn_norm_w; g.norm_b = w.attn_norm_b;

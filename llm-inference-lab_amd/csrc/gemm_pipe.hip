@@ -178,8 +178,6 @@ __device__ __noinline__ void pipe_row_stats(const uint16_t* xin, int T, int K, i
 
 template <int EPI, int TG, bool W8, int SC>
 __global__ __launch_bounds__(kGemvThreads) void gemm_pipe_kernel(const GemvArgs a, const PipeGeom pg) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   constexpr int KS = W8 ? 64 : 32;   // k per weight step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -204,6 +202,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_pipe_kernel(const GemvArgs 
   const int tile_pairs = a.tile_pairs;
   const int n_tiles = (p_lo + a.ppw <= a.n_pairs) ? a.n_tiles_full : (p_hi - p_lo + tile_pairs - 1) / tile_pairs;
   const int rounds = (n_tiles + tiles_per_round - 1) >> (4 - a.ks_shift);
+  // (here, not at entry: the arguments are needed from this point on anyway, so the check adds no wait of its own)
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
 
   // address of a lane's A fragment of global step gs: tile start + gs * wstride + lane_off
   int wstride = 32;

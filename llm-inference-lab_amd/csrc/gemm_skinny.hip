@@ -62,8 +62,6 @@ static int skinny_chunk(int T, int K, int ksplit, int kw, bool w8 = false) {
 // token group, widened to bf16 in registers as in gemv.hip; the row sum is scaled in the epilogue.
 template <int EPI, int TG, bool W8, int NB>
 __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArgs a, const SkinnyGeom sg) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   constexpr int KS = W8 ? 64 : 32;   // k per weight step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -84,6 +82,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
   const int sc_shift = sg.sc_shift, sc = 1 << sc_shift;
   const uint16_t* W = static_cast<const uint16_t*>(a.W);
 
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);   // (where the arguments are first needed: no wait of its own)
   const int p_lo = static_cast<int>(blockIdx.x) * a.ppw;
   const int p_hi = min(p_lo + a.ppw, a.n_pairs);
   const int tile_pairs = a.tile_pairs;
@@ -415,8 +414,6 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
 // ------------------------------------------------------------------------------
 template <int EPI, int TG>
 __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArgs a) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NB = (TG == 1) ? 10 : (TG == 2) ? 6 : (TG == 3) ? 5 : 4;   // steps per batch: NB * (1 + TG) 16-byte loads in flight per lane
   const int K = a.K, T = a.T;
@@ -435,6 +432,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArg
   const int p_hi = min(p_lo + a.ppw, a.n_pairs);
   const int tile_pairs = a.tile_pairs;
   const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;   // <= tiles_per_round (launcher)
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);   // (where the arguments are first needed: no wait of its own)
 
   // A fragment address: base + step * wstride + lane_off (as gemv.hip)
   int wstride = 32;
@@ -563,8 +561,6 @@ struct SliceCfg {
 
 template <int EPI, int TG>
 __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs a) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.W), "s"(a.K), "s"(a.T), "s"(a.x), "s"(a.ksplit), "s"(a.ppw), "s"(a.n_pairs));   // one scalar batch with the first fields the kernel needs
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   using C = SliceCfg<TG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
@@ -585,6 +581,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
   const int tile_pairs = a.tile_pairs;
   const int n_tiles = (p_hi - p_lo + tile_pairs - 1) / tile_pairs;   // <= tiles_per_round (launcher)
   const bool valid = tslot < n_tiles;
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);   // (where the arguments are first needed: no wait of its own)
 
   // A fragment address: base + step * wstride + lane_off (as gemv.hip); waves without a tile read tile 0 (L2 hits)
   int wstride = 32;

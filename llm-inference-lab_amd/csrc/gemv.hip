@@ -142,7 +142,6 @@ template <int EPI, bool MASK, int TT, bool W8, int KB>
 __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs a) {
   constexpr int kBatch = KB;
   pin_gemv_args<EPI, W8>(a);
-  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, T = a.T;
   const int KP = K + kXPad;
@@ -246,6 +245,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
     if (a.debug_ts && tid == 0) a.debug_ts[static_cast<size_t>(blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
+  // per-row adaptive K: a launch of a draft forward no row needs leaves here — after the index arithmetic above, which
+  // runs under the latency of the argument loads (at kernel entry the branch kept it behind them: 0.5 % of the step)
+  SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
 
   // ---- x staging, fast path (K <= 8192): thread `tid` owns the 16-byte chunk `tid` of every
   // token row. Its loads (x rows, norm weights, the residual value of its epilogue item) are

@@ -37,8 +37,9 @@ __device__ __forceinline__ void pin_gemv_args(const GemvArgs& a) {
   if constexpr (W8) SD_PIN("s"(a.w_scale));
   if constexpr (EPI == EPI_QKV_ROPE)
     SD_PIN("s"(a.head_dim), "s"(a.n_q_heads), "s"(a.n_kv_heads), "s"(a.pos_base), "s"(a.pos_off), "s"(a.rope_cos),
-           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max), "s"(a.half_shift));
-  if constexpr (EPI == EPI_ARGMAX) SD_PIN("s"(a.out_dtype), "s"(a.part_val), "s"(a.part_idx));
+           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max), "s"(a.half_shift),
+           "s"(a.block_table), "s"(a.page_shift), "s"(a.max_pages));   // (left out, the epilogue waited for a scalar load of its own: 0.5 % of the step)
+  if constexpr (EPI == EPI_ARGMAX) SD_PIN("s"(a.out_dtype), "s"(a.part_val), "s"(a.part_idx), "s"(a.batch_bytes));
 }
 
 // row indices of pair p for each epilogue
@@ -93,16 +94,26 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       // in-place KV append (the fused form of kv_append_ref, reference.py:59-93):
       // K rows are [Lmax][D], V is kept transposed [D][Lmax] (see attention.hip)
       const bool is_k = h < a.n_q_heads + a.n_kv_heads;
+      // dense: "page" b of l_max positions; paged: the row's page for this position, P positions each
+      size_t slab = static_cast<size_t>(b);
+      int off = pos, plen = a.l_max;
+#ifndef SD_NO_PAGED_EPI
+      if (a.block_table) {
+        slab = static_cast<size_t>(a.block_table[b * a.max_pages + (pos >> a.page_shift)]);
+        plen = 1 << a.page_shift;
+        off = pos & (plen - 1);
+      }
+#endif
       if (is_k) {
         const int kvh = h - a.n_q_heads;
-        uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * a.l_max + pos) * D + i;
+        uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + ((slab * a.n_kv_heads + kvh) * plen + off) * D + i;
         dst[0] = u0;
         dst[half] = u1;
       } else {
         const int kvh = h - a.n_q_heads - a.n_kv_heads;
-        uint16_t* dst = static_cast<uint16_t*>(a.v_cache) + ((static_cast<size_t>(b) * a.n_kv_heads + kvh) * D + i) * a.l_max + pos;
+        uint16_t* dst = static_cast<uint16_t*>(a.v_cache) + ((slab * a.n_kv_heads + kvh) * D + i) * plen + off;
         dst[0] = u0;
-        dst[static_cast<size_t>(half) * a.l_max] = u1;
+        dst[static_cast<size_t>(half) * plen] = u1;
       }
     }
   } else if constexpr (EPI == EPI_RESID) {

@@ -32,6 +32,10 @@ struct GemvArgs {
   int half_shift;    // log2(head_dim / 2), or -1 when head_dim / 2 is not a power of two (division fallback)
   unsigned m_magic;  // ceil(65536 / M): t / M == (t * m_magic) >> 16 for t < 65536 / M... (exact for t < 512)
   unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
+  // per-row adaptive K: a launch of draft forward skip_i leaves at once when *skip_k <= skip_i (null: never). (Here, among
+  // the fields every kernel loads first — at the end of the struct they cost the layer kernels one more scalar load.)
+  const int32_t* skip_k;
+  int skip_i;
   int packed;                    // W is in the packed tile-stream order of csrc/pack.hip
   int w8;                        // W holds OCP fp8 e4m3 values (packed only); acc of row r is scaled by w_scale[r]
   const float* w_scale;          // fp32 [N] row scales (w8)
@@ -60,6 +64,10 @@ struct GemvArgs {
   void* k_cache;            // [B][n_kv_heads][l_max][head_dim] bf16
   void* v_cache;
   int l_max;
+  // paged KV (sd_model_bind_paged): k_cache / v_cache are page POOLS ([pages][Hkv][P][D] / [pages][Hkv][D][P]) and row b's
+  // position pos lives in page block_table[b * max_pages + (pos >> page_shift)] at offset pos & (P - 1). null = dense rows.
+  const int32_t* block_table;
+  int page_shift, max_pages;
   // ARGMAX epilogue: per-workgroup partials [T][grid]
   float* part_val;
   int* part_idx;
@@ -75,8 +83,6 @@ struct GemvArgs {
   // blockIdx.y, over the SAME x rows; partials of matrix j at part_val/part_idx + j * T * grid. 0 = a single matrix.
   size_t batch_bytes;
   int n_batch;
-  const int32_t* skip_k;   // per-row adaptive K: launch of draft forward skip_i returns at entry when *skip_k <= skip_i (null: never)
-  int skip_i;
 };
 constexpr int kStatStride = 256;                    // partials per token (>= workgroups of the producing launch)
 constexpr int kStatPlane = kSkinnyMaxT * kStatStride;   // floats per plane (plane 0: sum of squares, plane 1: sum)
@@ -124,6 +130,8 @@ struct AttnArgs {
   void* out;            // bf16 [T][n_q_heads*head_dim]
   const int32_t* pos_base;
   int pos_off;
+  int skip_i;              // per-row adaptive K, as GemvArgs (next to the fields the kernel loads first)
+  const int32_t* skip_k;
   int B, M;
   int n_q_heads, n_kv_heads, head_dim, l_max;
   float scale;
@@ -133,8 +141,8 @@ struct AttnArgs {
   unsigned* split_cnt;
   int split_slots;      // partial tiles the workspace holds
   int n_split;          // set by launch_attention
-  const int32_t* skip_k;   // as GemvArgs
-  int skip_i;
+  const int32_t* block_table;   // paged KV, as GemvArgs (null = dense rows of l_max positions)
+  int page_shift, max_pages;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 constexpr int kAttnSplitSlots = 1024;   // partial tiles of the split-KV workspace

@@ -10,7 +10,6 @@ namespace sd {
 // x[t][:] = tok_emb[clamp(token[t])][:] (+ pos_emb[pos][:] for GPT-2)
 // clamp = validate_and_clamp_tokens, /root/reference/src/specdec/utils/token_validation.py:15-78
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
-  SD_PIN("s"(a.skip_k), "s"(a.skip_i), "s"(a.tokens), "s"(a.tok_emb), "s"(a.pos_base), "s"(a.x));
   SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
   const int t = blockIdx.x;
   const int b = t / a.M, m = t - b * a.M;

@@ -72,6 +72,8 @@ SIGNATURES = {
     "sd_model_workspace_bytes": (_c_size, [_c_void_p]),
     "sd_model_kv_bytes": (_c_size, [_c_void_p, _c_int, _c_int]),
     "sd_model_bind": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_size]),
+    "sd_model_kv_pool_bytes": (_c_size, [_c_void_p, _c_int, _c_int]),
+    "sd_model_bind_paged": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_size]),
     "sd_model_forward": (
         _c_int,
         [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,

@@ -53,9 +53,11 @@ class HipModel:
     """A decoder (Llama or GPT-2 shaped) bound to its KV cache on one GPU."""
 
     def __init__(self, weights: ModelWeights, batch: int, l_max: int, device: Optional[torch.device] = None,
-                 weight_dtype: str = "bf16"):
+                 weight_dtype: str = "bf16", page_len: Optional[int] = None, n_pages: Optional[int] = None):
         """weight_dtype "fp8": the engine streams an OCP e4m3 copy of the Linear weights (per-output-row
-        scales, quantised on the device at load); activations and the KV cache stay bf16."""
+        scales, quantised on the device at load); activations and the KV cache stay bf16.
+        page_len (a power of two >= 32): paged KV — the rows share a pool of `n_pages` pages (default: enough for every
+        row to reach l_max) through a block table; `reserve(row, length)` / `release(row)` manage a row's pages."""
         if weight_dtype not in ("bf16", "fp8"):
             raise ValueError(f"weight_dtype={weight_dtype!r} (bf16 or fp8)")
         self.weight_dtype = weight_dtype
@@ -105,6 +107,10 @@ class HipModel:
         _abi.check(self.lib.sd_model_create(ctypes.byref(mc), ctypes.byref(handle)), "sd_model_create")
         self.handle = handle
         self.batch, self.l_max = int(batch), (int(l_max) + 31) // 32 * 32  # whole 32-key blocks
+        self.page_len = None
+        if page_len is not None or os.environ.get("SPECDEC_PAGED_KV"):
+            self._bind_paged(int(page_len or os.environ["SPECDEC_PAGED_KV"]), n_pages)
+            return
         kv_bytes = self.lib.sd_model_kv_bytes(self.handle, self.batch, self.l_max)
         with torch.cuda.device(dev):
             # [n_layers][B][Hkv][Lmax][D] bf16 — sized for 288 GB of HBM: no paging, no realign copies
@@ -115,8 +121,62 @@ class HipModel:
                                               self.batch, self.l_max, self.workspace.data_ptr(),
                                               self.workspace.numel()), "sd_model_bind")
 
+    # ---- paged KV -----------------------------------------------------------------------------------------------
+    def _bind_paged(self, page_len: int, n_pages: Optional[int]) -> None:
+        P = int(page_len)
+        if P < 32 or P & (P - 1):
+            raise ValueError(f"page_len={P}: a power of two >= 32")
+        self.page_len = P
+        self.max_pages = (self.l_max + P - 1) // P
+        self.l_max = self.max_pages * P
+        self.n_pages = int(n_pages) if n_pages is not None else self.batch * self.max_pages
+        dev = self.device
+        pool = self.lib.sd_model_kv_pool_bytes(self.handle, self.n_pages, P)
+        with torch.cuda.device(dev):
+            self.k_cache = torch.zeros(pool // 2, dtype=torch.bfloat16, device=dev)
+            self.v_cache = torch.zeros(pool // 2, dtype=torch.bfloat16, device=dev)
+            # every entry names a valid page at all times (unreached entries are never read, but a clamped load may touch them)
+            self.block_table = torch.zeros(self.batch, self.max_pages, dtype=torch.int32, device=dev)
+            self.workspace = torch.empty(self.lib.sd_model_workspace_bytes(self.handle), dtype=torch.uint8, device=dev)
+            _abi.check(self.lib.sd_model_bind_paged(self.handle, self.k_cache.data_ptr(), self.v_cache.data_ptr(), self.n_pages, P,
+                                                    self.block_table.data_ptr(), self.max_pages, self.batch,
+                                                    self.workspace.data_ptr(), self.workspace.numel()), "sd_model_bind_paged")
+        self._free = list(range(self.n_pages - 1, -1, -1))       # stack of free page indices
+        self._owned: List[List[int]] = [[] for _ in range(self.batch)]
+
+    def reserve(self, row: int, length: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Make positions [0, length) of `row` addressable (paged engines; a no-op on dense ones). New table entries are
+        written on `stream` (default: the current stream) — the forward that uses them must be ordered after it."""
+        if self.page_len is None:
+            return
+        need = (min(int(length), self.l_max) + self.page_len - 1) // self.page_len
+        own = self._owned[row]
+        if need <= len(own):
+            return
+        if need - len(own) > len(self._free):
+            raise RuntimeError(f"KV page pool exhausted: row {row} needs {need - len(own)} more pages, {len(self._free)} free of {self.n_pages}")
+        first = len(own)
+        while len(own) < need:
+            own.append(self._free.pop())
+        new = torch.tensor(own[first:], dtype=torch.int32)
+        with torch.cuda.device(self.device), torch.cuda.stream(stream or torch.cuda.current_stream(self.device)):
+            self.block_table[row, first:need].copy_(new.to(self.device, non_blocking=False))
+
+    def release(self, row: int) -> None:
+        """Return the row's pages to the pool (its sequence is finished; the next reserve() starts from nothing)."""
+        if self.page_len is None:
+            return
+        self._free.extend(reversed(self._owned[row]))
+        self._owned[row] = []
+
+    def pages_in_use(self) -> int:
+        return 0 if self.page_len is None else self.n_pages - len(self._free)
+
     def kv_view(self):
         c = self.cfg
+        if self.page_len is not None:
+            return (self.k_cache.view(c.n_layers, self.n_pages, c.n_kv_heads, self.page_len, c.head_dim),
+                    self.v_cache.view(c.n_layers, self.n_pages, c.n_kv_heads, c.head_dim, self.page_len))
         k_shape = (c.n_layers, self.batch, c.n_kv_heads, self.l_max, c.head_dim)
         v_shape = (c.n_layers, self.batch, c.n_kv_heads, c.head_dim, self.l_max)  # V is kept transposed
         return self.k_cache.view(k_shape), self.v_cache.view(v_shape)
@@ -130,6 +190,9 @@ class HipModel:
         assert pos_base.dtype == torch.int32 and pos_base.shape == (tokens.shape[0],) and pos_base.device == self.device
         B, M = tokens.shape
         tokens = tokens.contiguous()
+        if self.page_len is not None:     # paged KV: the positions this pass writes must have pages (host-known here at the cost
+            for i, p0 in enumerate(pos_base.tolist()):   # of one read-back; the captured step loop reserves ahead instead)
+                self.reserve(row0 + i, p0 + int(pos_off) + M, stream=stream)
         ids = torch.empty((B, M), dtype=torch.int32, device=self.device) if (want_ids and not skip_head) else None
         logits = None
         if want_logits and not skip_head:

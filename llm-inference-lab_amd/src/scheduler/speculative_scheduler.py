@@ -34,10 +34,13 @@ class SpeculativeScheduler:
         self.use_event_sync = os.getenv("SPECDEC_SYNC_MODE", "event").lower() == "event"
         self.enable_multi_stream = bool(enable_multi_stream) and device == "cuda" and torch.cuda.is_available()
         self.enable_batched_verification = enable_batched_verification
-        self.verification_stream = torch.cuda.Stream() if self.enable_multi_stream else None
-        self.default_stream = torch.cuda.current_stream() if self.enable_multi_stream else None
-        self.verify_ready_event = (torch.cuda.Event(enable_timing=True)
-                                   if self.enable_multi_stream and self.use_event_sync else None)
+        # The reference creates a verification stream and an event here and overlaps its base pass with drafting
+        # (:123-190); that pass does not read the draft tokens. The one-pass verify does, so there is nothing to overlap
+        # (measured: profiles/round2_row_group_concurrency.md) and no stream or event is created — the attributes stay for
+        # callers that look at them.
+        self.verification_stream = None
+        self.default_stream = None
+        self.verify_ready_event = None
         self.kernels_available = True
         self.kernel_info = get_kernel_info()
         self.metrics = {"total_proposed": 0, "total_accepted": 0, "total_steps": 0,

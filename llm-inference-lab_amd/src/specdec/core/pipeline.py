@@ -697,6 +697,11 @@ class DecodeSession:
         for r in self.rows:
             if len(r.seq) + 2 * self.k + 4 > self.pos_limit:
                 raise ValueError(f"prompt of {len(r.seq)} tokens leaves no room for a step within {self.pos_limit} positions")
+        self._engines = [e for e in (self.rt["target"], self.rt["draft"]) if e is not None]
+        for e in self._engines:                 # paged KV: the previous session's pages go back to the pool
+            for b in range(len(self.rows)):
+                e.release(b)
+        self._fresh: set = set()                # rows whose slot was handed to a new sequence (admit)
         pipe._prefill(self.rt, self.rows)
         self.loop.join_current_stream()
         for b, r in enumerate(self.rows):
@@ -770,6 +775,10 @@ class DecodeSession:
         pipe, loop, rt = self.pipe, self.loop, self.rt
         for b, what in self._flagged.items():
             r = self.rows[b]
+            if b in self._fresh:                   # a new sequence in the slot: the old one's pages go back first (idle stream)
+                for e in self._engines:
+                    e.release(b)
+                self._fresh.discard(b)
             if what == "resync" and r.active:      # the host rules rewrote the row: rebuild its caches
                 pipe._prefill_row(rt, b, r.seq)
                 loop.join_current_stream()
@@ -792,6 +801,14 @@ class DecodeSession:
                 self._resample_state = False
                 self._apply_sampling()
         idx = self.loop.launches
+        if self._engines[0].page_len is not None:
+            # paged KV: the device advances by itself, so every row gets the pages of all the steps in flight plus this one
+            # before it is launched (table writes go to the loop's stream, ahead of the step). Frozen rows keep writing their
+            # K+1 positions in place and keep their pages until the slot is handed on.
+            reach = (len(self._queue) + 2) * (self.k + 1) + 2
+            for b, r in enumerate(self.rows):
+                for e in self._engines:
+                    e.reserve(b, len(r.seq) + reach, stream=self.loop.stream_t)
         self.loop.step(use_graph=True)
         self._queue.append((idx, set()))
 
@@ -904,6 +921,7 @@ class DecodeSession:
         if len(prompt) + self.max_tokens + 2 * self.k + 8 > self.rt["l_max"] or len(prompt) + 2 * self.k + 4 > self.pos_limit:
             raise ValueError(f"prompt of {len(prompt)} tokens does not fit this session (l_max {self.rt['l_max']}, positions {self.pos_limit})")
         self.rows[b] = _Row(list(prompt))
+        self._fresh.add(b)
         if self.per_row:
             self.row_ctl[b] = self._new_row_controller()
         self._flagged[b] = "resync"

@@ -54,7 +54,8 @@ class IdTokenizer:
 
 class HipLM(LanguageModel):
     def __init__(self, weights: W.ModelWeights, tokenizer: Any = None, name: Optional[str] = None,
-                 max_len: int = 1024, batch: int = 1, device: str = "cuda", weight_dtype: str = "bf16"):
+                 max_len: int = 1024, batch: int = 1, device: str = "cuda", weight_dtype: str = "bf16",
+                 kv_page_len: Optional[int] = None, kv_pages: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipLM needs a GPU: this build has no CPU compute path")
         self._device = torch.device(device if device != "auto" else "cuda")
@@ -65,6 +66,9 @@ class HipLM(LanguageModel):
         self._name = name or self.config.name
         self.weight_dtype = weight_dtype   # "fp8": the engines stream an e4m3 copy of the Linear weights
         self._max_len, self._batch = max_len, batch
+        # paged KV (sd_model_bind_paged): engines share a pool of kv_pages pages of kv_page_len positions instead of
+        # owning l_max positions per row (kv_pages None: enough for every row to reach l_max)
+        self.kv_page_len, self.kv_pages = kv_page_len, kv_pages
         self._model: Optional[HipModel] = None
         self._cached: List[List[int]] = []
         self._last_generated_kv: Optional[KVCache] = None
@@ -72,7 +76,8 @@ class HipLM(LanguageModel):
     # ---- engine instances ----------------------------------------------------------
     def new_engine(self, batch: int, l_max: int) -> HipModel:
         """A forward instance with its own KV cache over the shared weights."""
-        return HipModel(self.weights, batch=batch, l_max=l_max, device=self._device, weight_dtype=self.weight_dtype)
+        return HipModel(self.weights, batch=batch, l_max=l_max, device=self._device, weight_dtype=self.weight_dtype,
+                        page_len=self.kv_page_len, n_pages=self.kv_pages)
 
     def _engine(self, batch: int, need_len: int) -> HipModel:
         m = self._model
