@@ -81,7 +81,7 @@ int launch_attention(const AttnArgs& a_in, hipStream_t st) {
   SD_REQUIRE(a.n_kv_heads > 0 && a.n_q_heads % a.n_kv_heads == 0, "attention: Hq %% Hkv != 0");
   SD_REQUIRE(a.B >= 1 && a.M >= 1, "attention: empty batch");
   SD_REQUIRE(a.l_max % 8 == 0 && a.l_max >= 8, "attention: l_max=%d must be a multiple of 8", a.l_max);
-  SD_REQUIRE(!a.block_table || (a.page_shift >= 5 && a.page_shift <= 16 && a.max_pages >= 1 && a.l_max == (a.max_pages << a.page_shift)),
+  SD_REQUIRE(!a.block_table || (a.page_shift >= 5 && a.page_shift <= 16 && a.l_max >= (1 << a.page_shift) && a.l_max % (1 << a.page_shift) == 0),
              "attention: paged cache needs pages of 32 * 2^n positions and l_max = max_pages * page_len");
   const int G = a.n_q_heads / a.n_kv_heads;
   const int R = G * a.M;

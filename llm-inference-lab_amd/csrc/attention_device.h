@@ -102,7 +102,7 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
     const int key0 = blk * kAttnBlock;
     int kbase = key0;                       // position of the block's first key inside its slab
     if constexpr (PAGED) {
-      const int pg = __builtin_amdgcn_readfirstlane(a.block_table[b * a.max_pages + (key0 >> a.page_shift)]);
+      const int pg = __builtin_amdgcn_readfirstlane(a.block_table[b * (a.l_max >> a.page_shift) + (key0 >> a.page_shift)]);
       kc = static_cast<const uint16_t*>(a.k_cache) + ((static_cast<size_t>(pg) * a.n_kv_heads + kvh) << a.page_shift) * D;
       vt = static_cast<const uint16_t*>(a.v_cache) + ((static_cast<size_t>(pg) * a.n_kv_heads + kvh) * D << a.page_shift);
       kbase = key0 & (vstride - 1);

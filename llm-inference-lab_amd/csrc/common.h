@@ -47,7 +47,7 @@ namespace sd {
         "s_endpgm\n"                                                              \
         "1:"                                                                      \
         : "=&s"(sd_skip_tmp_)                                                     \
-        : "s"(kptr), "s"(level)                                                   \
+        : "s"(kptr), "s"(static_cast<int>(level))                                 \
         : "scc");                                                                 \
   } while (0)
 #endif

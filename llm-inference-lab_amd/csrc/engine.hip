@@ -138,7 +138,6 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     g.w8 = m->w8();
     g.block_table = bt;
     g.page_shift = m->page_shift;
-    g.max_pages = m->max_pages;
     g.skip_k = m->skip_k;
     g.skip_i = m->skip_i;
 
@@ -187,7 +186,6 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     at.split_slots = kAttnSplitSlots;
     at.block_table = bt;
     at.page_shift = m->page_shift;
-    at.max_pages = m->max_pages;
     at.skip_k = m->skip_k;
     at.skip_i = m->skip_i;
     if (int rc = launch_attention(at, st)) return rc;

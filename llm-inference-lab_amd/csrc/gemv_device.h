@@ -30,16 +30,18 @@ __device__ __forceinline__ float gelu_new(float x) {
 // (SD_PIN: common.h)
 template <int EPI, bool W8>
 __device__ __forceinline__ void pin_gemv_args(const GemvArgs& a) {
-  SD_PIN("s"(a.W), "s"(a.K), "s"(a.T), "s"(a.kw), "s"(a.ppw), "s"(a.tile_pairs), "s"(a.ksplit), "s"(a.alias_part),
-         "s"(a.debug_ts), "s"(a.packed), "s"(a.n_pairs), "s"(a.x), "s"(a.x_stride), "s"(a.x_row), "s"(a.prologue),
-         "s"(a.norm_w), "s"(a.norm_b), "s"(a.norm_eps), "s"(a.out), "s"(a.out_stride), "s"(a.M), "s"(a.bias), "s"(a.N),
-         "s"(a.ks_shift), "s"(a.n_tiles_full), "s"(a.m_magic), "s"(a.skip_k), "s"(a.skip_i));
+  SD_PIN("s"(a.W), "s"(a.x), "s"(a.out), "s"(a.norm_w), "s"(a.norm_b), "s"(a.bias), "s"(a.x_row), "s"(a.skip_k), "s"(a.debug_ts),
+         "s"(a.N), "s"(a.K), "s"(a.n_pairs), "s"(a.kw), "s"(a.x_stride), "s"(a.out_stride), "s"(a.m_magic), "s"(a.norm_eps),
+         "s"(static_cast<int>(a.T)), "s"(static_cast<int>(a.M)), "s"(static_cast<int>(a.ppw)), "s"(static_cast<int>(a.n_tiles_full)),
+         "s"(static_cast<int>(a.tile_pairs)), "s"(static_cast<int>(a.ksplit)), "s"(static_cast<int>(a.alias_part)),
+         "s"(static_cast<int>(a.packed)), "s"(static_cast<int>(a.prologue)), "s"(static_cast<int>(a.ks_shift)),
+         "s"(static_cast<int>(a.skip_i)));
   if constexpr (W8) SD_PIN("s"(a.w_scale));
   if constexpr (EPI == EPI_QKV_ROPE)
-    SD_PIN("s"(a.head_dim), "s"(a.n_q_heads), "s"(a.n_kv_heads), "s"(a.pos_base), "s"(a.pos_off), "s"(a.rope_cos),
-           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max), "s"(a.half_shift),
-           "s"(a.block_table), "s"(a.page_shift), "s"(a.max_pages));   // (left out, the epilogue waited for a scalar load of its own: 0.5 % of the step)
-  if constexpr (EPI == EPI_ARGMAX) SD_PIN("s"(a.out_dtype), "s"(a.part_val), "s"(a.part_idx), "s"(a.batch_bytes));
+    SD_PIN("s"(static_cast<int>(a.head_dim)), "s"(static_cast<int>(a.n_q_heads)), "s"(static_cast<int>(a.n_kv_heads)), "s"(a.pos_base), "s"(a.pos_off), "s"(a.rope_cos),
+           "s"(a.rope_sin), "s"(a.max_pos), "s"(a.k_cache), "s"(a.v_cache), "s"(a.l_max), "s"(static_cast<int>(a.half_shift)),
+           "s"(a.block_table), "s"(static_cast<int>(a.page_shift)));   // (left out, the epilogue waited for a scalar load of its own: 0.5 % of the step)
+  if constexpr (EPI == EPI_ARGMAX) SD_PIN("s"(static_cast<int>(a.out_dtype)), "s"(a.part_val), "s"(a.part_idx), "s"(a.batch_bytes));
 }
 
 // row indices of pair p for each epilogue
@@ -99,7 +101,7 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       int off = pos, plen = a.l_max;
 #ifndef SD_NO_PAGED_EPI
       if (a.block_table) {
-        slab = static_cast<size_t>(a.block_table[b * a.max_pages + (pos >> a.page_shift)]);
+        slab = static_cast<size_t>(a.block_table[b * (a.l_max >> a.page_shift) + (pos >> a.page_shift)]);
         plen = 1 << a.page_shift;
         off = pos & (plen - 1);
       }

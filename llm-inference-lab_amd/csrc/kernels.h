@@ -15,74 +15,77 @@ constexpr int kGemvMaxT = 9;     // tokens per launch of gemv.hip (K+1 for K = 8
 constexpr int kSkinnyMaxT = 128; // tokens per launch of gemm_skinny.hip (batched verify, chunked prefill)
 
 struct GemvArgs {
-  // weights: bf16 [N][K] row-major
-  const void* W;
-  const void* bias;  // bf16 [N] or null
+  // Field ORDER and WIDTHS are part of the design: these kernels are latency chains, every launch starts by pulling its
+  // arguments through the scalar cache, and each further 64-byte line of the argument block that the first instructions
+  // touch is a further miss (measured: two fields appended at byte 320 instead of byte 72 cost 0.8 % of the batch-1 step).
+  // Lines 0 and 1 hold what EVERY variant needs before its first loads; the epilogue-specific fields follow.
+  // ---- line 0: pointers
+  const void* W;         // weights: bf16 [N][K] row-major, or the packed tile streams of csrc/pack.hip
+  const void* x;         // activations in: bf16 [T][x_stride]
+  void* out;             // q buffer / residual stream / activation / logits (may be null for ARGMAX)
+  const void* norm_w;    // fused normalisation of x
+  const void* norm_b;
+  const void* bias;      // bf16 [N] or null
+  const int32_t* x_row;  // nullable, device [T]: token t reads row x_row[t] of x instead of row t (gemv.hip only)
+  // per-row adaptive K: a launch of draft forward skip_i leaves at once when *skip_k <= skip_i (null: never)
+  const int32_t* skip_k;
+  // ---- line 1: scalars
+  unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
   int N, K;
   int n_pairs;       // row pairs processed (see pair_rows)
   int kw;            // K span per slice (set by launch_gemv)
-  int ppw;           // pairs per workgroup (set by launch_gemv)
-  int tile_pairs;    // pairs per tile, <= 8 (set by launch_gemv)
-  int ksplit;        // K slices per tile, power of two <= 16 (set by launch_gemv)
-  int alias_part;    // partial sums alias the staged x rows (set by launch_gemv)
-  // derived by the launchers (gemv_derive): the kernels' index arithmetic without runtime integer divisions — a
-  // division is ~25 instructions with a transcendental, and five of them sat between wave entry and the first weight load
-  int ks_shift;      // log2(ksplit)
-  int n_tiles_full;  // tiles of a workgroup that owns a full share of ppw pairs
-  int half_shift;    // log2(head_dim / 2), or -1 when head_dim / 2 is not a power of two (division fallback)
-  unsigned m_magic;  // ceil(65536 / M): t / M == (t * m_magic) >> 16 for t < 65536 / M... (exact for t < 512)
-  unsigned long long* debug_ts;  // diagnostic timeline stamps [grid][8] or null
-  // per-row adaptive K: a launch of draft forward skip_i leaves at once when *skip_k <= skip_i (null: never). (Here, among
-  // the fields every kernel loads first — at the end of the struct they cost the layer kernels one more scalar load.)
-  const int32_t* skip_k;
-  int skip_i;
-  int packed;                    // W is in the packed tile-stream order of csrc/pack.hip
-  int w8;                        // W holds OCP fp8 e4m3 values (packed only); acc of row r is scaled by w_scale[r]
-  const float* w_scale;          // fp32 [N] row scales (w8)
-  // activations in: bf16 [T][x_stride]
-  const void* x;
   int x_stride;
-  const int32_t* x_row;  // nullable, device [T]: token t reads row x_row[t] of x instead of row t (gemv.hip only)
-  int T;             // tokens in this pass
-  int M;             // tokens per batch row (t = b*M + m)
-  // fused normalisation of x
-  int prologue;
-  const void* norm_w;
-  const void* norm_b;
-  float norm_eps;
-  // outputs
-  void* out;         // q buffer / residual stream / activation / logits (may be null for ARGMAX)
   int out_stride;
-  int out_dtype;     // SD_BF16 | SD_F32 (logits only)
-  // QKV epilogue
-  int head_dim, n_q_heads, n_kv_heads;
+  unsigned m_magic;  // ceil(65536 / M): t / M == (t * m_magic) >> 16 for t < 65536 / M... (exact for t < 512)
+  float norm_eps;
+  // small scalars as bitfields of 32-bit units (plain uint8_t / uint16_t kernel-argument fields made hipcc fetch some of
+  // them with VECTOR byte loads; a bitfield is read as its dword through the scalar cache and extracted with s_bfe)
+  unsigned T : 8;             // tokens in this pass (<= kSkinnyMaxT)
+  unsigned M : 8;             // tokens per batch row (t = b*M + m)
+  unsigned ppw : 16;          // pairs per workgroup (set by launch_gemv)
+  unsigned n_tiles_full : 16; // tiles of a workgroup that owns a full share of ppw pairs
+  unsigned tile_pairs : 4;    // pairs per tile, <= 8 (set by launch_gemv)
+  unsigned ksplit : 5;        // K slices per tile, power of two <= 16 (set by launch_gemv)
+  unsigned ks_shift : 3;      // log2(ksplit)   (derived by the launchers, gemv_derive: index arithmetic without runtime divisions)
+  unsigned alias_part : 1;    // partial sums alias the staged x rows (set by launch_gemv)
+  unsigned packed : 1;        // W is in the packed tile-stream order of csrc/pack.hip
+  unsigned w8 : 1;            // W holds OCP fp8 e4m3 values (packed only); acc of row r is scaled by w_scale[r]
+  unsigned : 1;
+  unsigned prologue : 2;      // GemvPrologue
+  unsigned out_dtype : 2;     // SD_BF16 | SD_F32 (logits only)
+  unsigned skip_i : 4;
+  int half_shift : 8;         // log2(head_dim / 2), or -1 when head_dim / 2 is not a power of two (division fallback)
+  // ---- epilogue-specific
+  const float* w_scale;          // fp32 [N] row scales (w8)
+  // QKV epilogue: one 64-byte line (bytes 128..191)
   const int32_t* pos_base;  // device [B]
-  int pos_off;
   const float* rope_cos;    // [max_pos][head_dim/2] or null (no RoPE)
   const float* rope_sin;
-  int max_pos;
   void* k_cache;            // [B][n_kv_heads][l_max][head_dim] bf16
   void* v_cache;
-  int l_max;
   // paged KV (sd_model_bind_paged): k_cache / v_cache are page POOLS ([pages][Hkv][P][D] / [pages][Hkv][D][P]) and row b's
-  // position pos lives in page block_table[b * max_pages + (pos >> page_shift)] at offset pos & (P - 1). null = dense rows.
+  // position pos lives in page block_table[b * (l_max >> page_shift) + (pos >> page_shift)] at offset pos & (P - 1).
+  // null = dense rows of l_max positions.
   const int32_t* block_table;
-  int page_shift, max_pages;
+  int pos_off;
+  int max_pos;
+  int l_max;
+  unsigned head_dim : 8, n_q_heads : 8, n_kv_heads : 8, page_shift : 8;
   // ARGMAX epilogue: per-workgroup partials [T][grid]
   float* part_val;
   int* part_idx;
+  // EPI_ARGMAX, gemv.hip only: n_batch equally shaped matrices at a constant byte stride (the K Medusa heads), one per
+  // blockIdx.y, over the SAME x rows; partials of matrix j at part_val/part_idx + j * T * grid. 0 = a single matrix.
+  size_t batch_bytes;
+  int n_batch;
   // Row statistics handed from the kernel that WRITES the residual stream to the kernel that normalises it (> 9 tokens):
   // an EPI_RESID launch with xstat_out != null leaves, per token t and workgroup c, the sum of squares and the sum of the
   // new row values over the columns c owns: xstat_out[t * kStatStride + c] and xstat_out[kStatPlane + t * kStatStride + c].
   // A norm-fused launch with xstat_in != null adds the xstat_n partials of a token in a fixed order instead of reading
   // the whole row again (every one of its 256 workgroups would: 63 MB of L2 -> CU traffic at 40 tokens, 6-9 us).
+  int xstat_n;
   float* xstat_out;
   const float* xstat_in;
-  int xstat_n;
-  // EPI_ARGMAX, gemv.hip only: n_batch equally shaped matrices at a constant byte stride (the K Medusa heads), one per
-  // blockIdx.y, over the SAME x rows; partials of matrix j at part_val/part_idx + j * T * grid. 0 = a single matrix.
-  size_t batch_bytes;
-  int n_batch;
 };
 constexpr int kStatStride = 256;                    // partials per token (>= workgroups of the producing launch)
 constexpr int kStatPlane = kSkinnyMaxT * kStatStride;   // floats per plane (plane 0: sum of squares, plane 1: sum)
@@ -124,25 +127,26 @@ int launch_gemm_pipe(const GemvArgs& a, const GemvGeom& q, int epi, hipStream_t 
 
 // ---- attention over the appended KV cache (attention.hip) -------------------------
 struct AttnArgs {
+  // line 0 (64 bytes): everything a short-context launch reads (see GemvArgs on why the order matters)
   const void* q;        // bf16 [T][n_q_heads*head_dim]
   const void* k_cache;  // bf16 [B][n_kv_heads][l_max][head_dim]
   const void* v_cache;
   void* out;            // bf16 [T][n_q_heads*head_dim]
   const int32_t* pos_base;
+  const int32_t* skip_k;   // per-row adaptive K, as GemvArgs
   int pos_off;
-  int skip_i;              // per-row adaptive K, as GemvArgs (next to the fields the kernel loads first)
-  const int32_t* skip_k;
-  int B, M;
-  int n_q_heads, n_kv_heads, head_dim, l_max;
+  int l_max;
   float scale;
+  unsigned M : 8, n_q_heads : 8, n_kv_heads : 8, n_split : 8;   // n_split: set by launch_attention
+  // line 1
+  unsigned head_dim : 8, page_shift : 8, skip_i : 4;
+  int B;
   // split-KV over workgroups for long contexts (attention.hip): partial (max, sum, O) tiles and one
   // arrival counter per (row, kv head, query tile); null / 0 = every tile is one workgroup
   float* split_ws;
   unsigned* split_cnt;
   int split_slots;      // partial tiles the workspace holds
-  int n_split;          // set by launch_attention
   const int32_t* block_table;   // paged KV, as GemvArgs (null = dense rows of l_max positions)
-  int page_shift, max_pages;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 constexpr int kAttnSplitSlots = 1024;   // partial tiles of the split-KV workspace
