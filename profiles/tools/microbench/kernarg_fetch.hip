@@ -1,0 +1,113 @@
+// What does a kernel pay for reading its arguments? A chain of dependent launches (one hipGraph, 256 workgroups x 1024
+// threads like the weight-streaming kernels) whose body is: nothing / read one field of a 256-byte by-value argument block /
+// read it from a device-memory block behind a pointer (cold: a different block per launch; warm: the previous launch touched
+// it) / the same pointer with the hardware's kernarg preload.
+//   hipcc --offload-arch=gfx950 -O3 kernarg_fetch.hip -o kernarg_fetch && ./kernarg_fetch
+//   hipcc ... -mllvm -amdgpu-kernarg-preload-count=4 -DPRELOAD ... (second binary)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("%s: %s\n", #x, hipGetErrorString(e_));                           \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+struct Block {
+  const void* p[8];
+  int v[48];
+};
+static_assert(sizeof(Block) == 256, "256-byte block");
+
+__global__ __launch_bounds__(1024) void k_empty() {}
+
+__global__ __launch_bounds__(1024) void k_byvalue(const Block b, int* sink) {
+  if (b.v[0] == 0x7fffffff) sink[0] = b.v[47];   // one field of the first line (and never true)
+}
+
+__global__ __launch_bounds__(1024) void k_byvalue_all(const Block b, int* sink) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 48; i += 16) s += b.v[i];  // a field of each of lines 0..3
+  if (s == 0x7fffffff) sink[0] = s;
+}
+
+// arguments behind a pointer; `next` = the block of the launch that follows (touched here so that it is in this XCD's L2)
+__global__ __launch_bounds__(1024) void k_pointer(const Block* b, const Block* next, int* sink) {
+  int warm = 0;
+  if (next) warm = __builtin_nontemporal_load(&next->v[0]);
+  const int v = b->v[0];
+  if (v == 0x7fffffff || warm == 0x7ffffffe) sink[0] = v;
+}
+
+// evict the L2s between two launches, like the weight streams of a decode step do: read 128 MiB
+__global__ __launch_bounds__(1024) void k_evict(const uint4* buf, size_t n, int* sink) {
+  uint4 acc = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * 1024 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 1024) {
+    const uint4 v = buf[i];
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[1] = 1;
+}
+
+template <typename F>
+static int run(const char* name, int n, hipStream_t st, F enqueue) {
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  for (int i = 0; i < n; ++i) enqueue(i);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, st));
+  CK(hipEventRecord(e0, st));
+  const int reps = 20;
+  for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("%-58s %6.3f us per launch\n", name, ms * 1000.0f / (reps * n));
+  return 0;
+}
+
+int main() {
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  const int n = 400;
+  int* sink;
+  CK(hipMalloc(&sink, 64));
+  // cold arena: blocks 1 MiB apart; a 1 GiB buffer is streamed between replays?  No: the replays themselves are the test —
+  // 400 launches x 20 replays, each launch its own block; L2 keeps them across replays unless evicted, so ALSO run with an
+  // evicting kernel between the launches (a 64 MiB read) to emulate the weight stream.
+  Block* arena;
+  CK(hipMalloc(&arena, sizeof(Block) * 4096 * (n + 1)));
+  CK(hipMemset(arena, 0, sizeof(Block) * 4096 * (n + 1)));
+  Block hb{};
+  const dim3 grid(256), blk(1024);
+  if (run("empty body", n, st, [&](int) { hipLaunchKernelGGL(k_empty, grid, blk, 0, st); })) return 1;
+  if (run("by-value 256-byte block, one field of line 0", n, st, [&](int i) { hb.v[1] = i; hipLaunchKernelGGL(k_byvalue, grid, blk, 0, st, hb, sink); })) return 1;
+  if (run("by-value 256-byte block, a field of each of 4 lines", n, st, [&](int i) { hb.v[1] = i; hipLaunchKernelGGL(k_byvalue_all, grid, blk, 0, st, hb, sink); })) return 1;
+  if (run("pointer to a device block (own block per launch)", n, st, [&](int i) { hipLaunchKernelGGL(k_pointer, grid, blk, 0, st, arena + 4096 * i, (const Block*)nullptr, sink); })) return 1;
+  if (run("pointer, block touched by the previous launch", n, st, [&](int i) { hipLaunchKernelGGL(k_pointer, grid, blk, 0, st, arena + 4096 * i, (const Block*)(arena + 4096 * (i + 1)), sink); })) return 1;
+  // the same with the L2s evicted before every launch (numbers include the 128 MiB read: compare the rows with each other)
+  uint4* big;
+  const size_t big_n = (128u << 20) / 16;
+  CK(hipMalloc(&big, big_n * 16));
+  CK(hipMemset(big, 1, big_n * 16));
+  const int m = 100;
+  auto ev = [&]() { hipLaunchKernelGGL(k_evict, grid, blk, 0, st, big, big_n, sink); };
+  if (run("[evict] + empty body", m, st, [&](int) { ev(); hipLaunchKernelGGL(k_empty, grid, blk, 0, st); })) return 1;
+  if (run("[evict] + by-value block, one field of line 0", m, st, [&](int i) { ev(); hb.v[1] = i; hipLaunchKernelGGL(k_byvalue, grid, blk, 0, st, hb, sink); })) return 1;
+  if (run("[evict] + by-value block, a field of each of 4 lines", m, st, [&](int i) { ev(); hb.v[1] = i; hipLaunchKernelGGL(k_byvalue_all, grid, blk, 0, st, hb, sink); })) return 1;
+  if (run("[evict] + pointer to a device block", m, st, [&](int i) { ev(); hipLaunchKernelGGL(k_pointer, grid, blk, 0, st, arena + 4096 * i, (const Block*)nullptr, sink); })) return 1;
+  if (run("[evict] + empty body (again)", m, st, [&](int) { ev(); hipLaunchKernelGGL(k_empty, grid, blk, 0, st); })) return 1;
+  return 0;
+}
