@@ -55,6 +55,22 @@ __global__ __launch_bounds__(1024) void k_evict(const uint4* buf, size_t n, int*
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[1] = 1;
 }
 
+// the same, and before it ends every workgroup touches the lines that FOLLOW its own argument block in the graph's
+// kernarg pool (consecutive nodes are laid out back to back: kernarg_addr.hip), i.e. the next launch's arguments
+__global__ __launch_bounds__(1024) void k_evict_pf(const uint4* buf, size_t n, int* sink) {
+  uint4 acc = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * 1024 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 1024) {
+    const uint4 v = buf[i];
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  int w = 0;
+  if (threadIdx.x < 8) {
+    const char* me = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    w = __builtin_nontemporal_load(reinterpret_cast<const int*>(me + 128 + 64 * threadIdx.x));
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u || w == 0x7ffffffe) sink[1] = 1;
+}
+
 template <typename F>
 static int run(const char* name, int n, hipStream_t st, F enqueue) {
   hipGraph_t g;
@@ -109,5 +125,9 @@ int main() {
   if (run("[evict] + by-value block, a field of each of 4 lines", m, st, [&](int i) { ev(); hb.v[1] = i; hipLaunchKernelGGL(k_byvalue_all, grid, blk, 0, st, hb, sink); })) return 1;
   if (run("[evict] + pointer to a device block", m, st, [&](int i) { ev(); hipLaunchKernelGGL(k_pointer, grid, blk, 0, st, arena + 4096 * i, (const Block*)nullptr, sink); })) return 1;
   if (run("[evict] + empty body (again)", m, st, [&](int) { ev(); hipLaunchKernelGGL(k_empty, grid, blk, 0, st); })) return 1;
+  auto evp = [&]() { hipLaunchKernelGGL(k_evict_pf, grid, blk, 0, st, big, big_n, sink); };
+  if (run("[evict + touch next args] + empty body", m, st, [&](int) { evp(); hipLaunchKernelGGL(k_empty, grid, blk, 0, st); })) return 1;
+  if (run("[evict + touch next args] + by-value block, line 0", m, st, [&](int i) { evp(); hb.v[1] = i; hipLaunchKernelGGL(k_byvalue, grid, blk, 0, st, hb, sink); })) return 1;
+  if (run("[evict + touch next args] + by-value block, 4 lines", m, st, [&](int i) { evp(); hb.v[1] = i; hipLaunchKernelGGL(k_byvalue_all, grid, blk, 0, st, hb, sink); })) return 1;
   return 0;
 }
