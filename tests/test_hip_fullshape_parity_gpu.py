@@ -103,3 +103,50 @@ def test_forward_logits_at_production_layer_shapes(name, monkeypatch):
             e_max, e_rms = _errs(kc[li, b, :, :n].float().cpu(), want_k[b][li][:, :n])
             assert e_max < 0.03 and e_rms < 0.015, (name, "k cache", b, li, e_max, e_rms)
     print(f"[fullshape] {name}: worst max-err {worst[0]:.4f} rms-err {worst[1]:.4f}")
+
+
+LONG = {
+    # the attention instantiations of the bench models at contexts where the keys of a tile are shared by several workgroups
+    # (split-KV, merged by the last arrival through the workspace both layers reuse); the MLP is narrowed to keep the CPU oracle
+    # at a few seconds — the attention geometry (heads, head_dim, GQA ratio) is the real one
+    "3b-heads-D128": dataclasses.replace(W.LLAMA_3_2_3B, n_layers=2, d_ff=1024, vocab=2048, max_pos=8192),
+    "1b-heads-D64": dataclasses.replace(W.LLAMA_3_2_1B, n_layers=2, d_ff=1024, vocab=2048, max_pos=8192),
+}
+
+
+@pytest.mark.parametrize("name", list(LONG))
+def test_split_kv_attention_at_production_head_dims_and_4k_keys(name, monkeypatch):
+    """>= 4 K keys, s_eff > 1, D = 64 / 128, two consecutive layers through the same partial-tile workspace and arrival
+    counters: logits of a 5-token verify-shaped pass against the bf16 oracle (3 % max / 1.5 % RMS), against the
+    one-workgroup-per-tile path, and bit-identical when repeated (the counters are back at zero)."""
+    from specdec_hip.engine import HipModel
+
+    cfg = LONG[name]
+    mw_dev = W.random_init(cfg, seed=7, device="cuda")
+    lm = OracleLM(mw_dev.to("cpu"), "bf16")
+    lens, M = [4200, 700], 5
+    g = torch.Generator().manual_seed(11)
+    seqs = [torch.randint(0, cfg.vocab, (n + M,), generator=g) for n in lens]
+    outs = {}
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("SPECDEC_NO_ATTN_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("SPECDEC_NO_ATTN_SPLIT", "1")
+        hm = HipModel(mw_dev, batch=len(lens), l_max=4608)
+        zero1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for b, (n, s) in enumerate(zip(lens, seqs)):
+            hm.forward(s[:n].to(torch.int32).view(1, -1).cuda(), zero1, 0, skip_head=True, row0=b)
+        new = torch.stack([s[n:] for n, s in zip(lens, seqs)], 0).to(torch.int32).cuda()
+        pos = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        ids, logits = hm.forward(new, pos, 0, want_logits=True)
+        ids2, logits2 = hm.forward(new, pos, 0, want_logits=True)
+        assert torch.equal(ids, ids2) and torch.equal(logits, logits2)
+        outs[split] = (ids.cpu().long(), logits.float().cpu())
+    for b, (n, s) in enumerate(zip(lens, seqs)):
+        want, _ = lm.forward(s.view(1, -1))
+        e_max, e_rms = _errs(outs[True][1][b], want[0, n:])
+        assert e_max < 0.03 and e_rms < 0.015, (name, b, e_max, e_rms)
+        assert torch.equal(outs[True][0][b], outs[True][1][b].argmax(-1))
+    e_max, e_rms = _errs(outs[True][1], outs[False][1])
+    assert e_max < 0.02 and e_rms < 0.01, (name, e_max, e_rms)   # two summation orders of bf16-rounded partials
