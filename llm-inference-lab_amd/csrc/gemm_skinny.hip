@@ -627,13 +627,19 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
 
   struct Set { u32x4 w[C::NWS]; u32x4 x[C::NX]; };
   Set A, B;
-  auto issue = [&](Set& s, int c) {                      // unconditional: sub-slices past the end re-read the last one
-    const int cc = c < nsub ? c : nsub - 1;
+  // Unconditional (a conditional load would cost the counted waits), but the loads of sub-slices past the end — up to two
+  // sets at the tail of the two-set pipeline, 40 % of all loads when a wave owns three sub-slices — are pointed at ONE
+  // line (offset 0 of the wave's slice, by masking the offsets: no branch): the kernel is bound by what a CU can pull
+  // through its L1 (~55-60 GB/s measured), and a re-read of a whole sub-slice cost as much as a real one.
+  auto issue = [&](Set& s, int c) {
+    const unsigned live = c < nsub ? 0xffffffffu : 0u;   // wave-uniform
+    const unsigned xcol = static_cast<unsigned>(c * C::W) & live;
+    const unsigned wstep = static_cast<unsigned>(c * C::NWS) & live;
 #pragma unroll
-    for (int i = 0; i < C::NX; ++i) s.x[i] = *reinterpret_cast<const u32x4*>(xin + xoff[i] + cc * C::W);
+    for (int i = 0; i < C::NX; ++i) s.x[i] = *reinterpret_cast<const u32x4*>(xin + ((xoff[i] & live) + xcol));
 #pragma unroll
     for (int j = 0; j < C::NWS; ++j)
-      s.w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + static_cast<size_t>(cc * C::NWS + j) * wstride + lane_off));
+      s.w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (static_cast<size_t>(wstep + j) * wstride + (lane_off & live))));
   };
   f32x4_t acc[TG];
 #pragma unroll
@@ -659,8 +665,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
     asm volatile("" ::: "memory");        \
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
+  // diagnostic timeline (sd_model_probe_gemv with SPECDEC_GEMV_TIMELINE=1), stamps of thread 0: 0 entry, 1 first set issued,
+  // 3 K loop done, 4 partials exchanged, 5 epilogue, 6 end
+  auto stamp = [&](int slot) {
+    if (a.debug_ts && tid == 0) a.debug_ts[static_cast<size_t>(blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   issue(A, 0);
   SD_PIN_ORDER();
+  stamp(1);
   for (int c = 0; c < nsub; c += 2) {
     issue(B, c + 1);
     SD_PIN_ORDER();
@@ -673,12 +686,14 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
   }
 #undef SD_PIN_ORDER
 
+  stamp(3);
   float* slot = part + static_cast<size_t>(wave) * TG * 256;
 #pragma unroll
   for (int q = 0; q < TG; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) slot[q * 256 + (4 * g + e) * 16 + n] = valid ? acc[q][e] : 0.f;
   __syncthreads();
+  stamp(4);
   float best_v[TG];
   int best_i[TG];
 #pragma unroll
@@ -714,9 +729,11 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
       }
     }
   }
+  stamp(5);
   // the wave-private x regions are dead (every wave passed the barrier above): scratch for the row statistics
   if constexpr (EPI == EPI_RESID)
     if (a.xstat_out) resid_stats_publish<TG>(a, st_sq, st_sum, reinterpret_cast<float*>(smem), tid);
+  stamp(6);
 }
 
 template <int EPI, int TG>
