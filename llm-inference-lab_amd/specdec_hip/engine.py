@@ -77,6 +77,9 @@ class HipModel:
             if t.dtype != want or not t.is_contiguous():
                 raise TypeError(f"weight {name}: need contiguous {want}, got {t.dtype} contiguous={t.is_contiguous()}")
         c = self.cfg
+        if not (1 <= c.n_kv_heads <= c.n_heads <= 255 and c.head_dim in (32, 64, 128)):
+            # (the kernels' argument blocks carry these in 8-bit fields)
+            raise ValueError(f"unsupported attention geometry: {c.n_heads} heads / {c.n_kv_heads} kv heads / head_dim {c.head_dim}")
         self._layers = (_LayerWeights * c.n_layers)()
         for i, l in enumerate(weights.layers):
             for f, _ in _LayerWeights._fields_:
