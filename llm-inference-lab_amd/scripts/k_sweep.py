@@ -153,6 +153,28 @@ def run(args, base=None, draft=None):
     return results, detailed
 
 
+def write_manifest(out_dir, csv_file, json_file, args) -> Path:
+    """MANIFEST.json of a results directory, the keys of the reference's exported runs
+    (docs/results/2025-10-30-T4-Phase3D-Run1-32tok-100iter-fp16/MANIFEST.json; layout: docs/progress.md:966-984)."""
+    import torch
+
+    dev = torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu"
+    man = {
+        "export_created_at": datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
+        "device": dev,
+        "dtype": "bfloat16",
+        "max_tokens": int(args.max_tokens),
+        "iterations_per_k": int(args.iterations),
+        "models": {"base": args.base_model, "draft": args.draft_model},
+        "artifacts": {"summary_json": Path(json_file).name, "summary_csv": Path(csv_file).name},
+        "source_dir": str(Path(out_dir).resolve()),
+    }
+    path = Path(out_dir) / "MANIFEST.json"
+    with open(path, "w") as f:
+        json.dump(man, f, indent=2)
+    return path
+
+
 def save(results, detailed, out_dir, batch_size: int = 1):
     ts = datetime.now().strftime("%Y%m%d_%H%M%S")
     out = Path(out_dir)
@@ -189,4 +211,5 @@ if __name__ == "__main__":
     t0 = time.time()
     res, det = run(a)
     c, j = save(res, det, a.output_dir, int(os.getenv("SPECDEC_BATCH_SIZE", str(a.batch_size))))
-    print(f"saved {c} and {j} in {time.time() - t0:.1f}s")
+    m = write_manifest(a.output_dir, c, j, a)
+    print(f"saved {c}, {j} and {m} in {time.time() - t0:.1f}s")

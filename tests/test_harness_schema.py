@@ -77,3 +77,18 @@ def test_k_sweep_files_have_the_reference_schema(tmp_path, capsys):
             assert kind(ours[k]) == {"float64": "float"}.get(t, t), (k, type(ours[k]).__name__, t)
     assert list(results[0].keys()) == list(g["summary_row"].keys())          # same column order
     assert written["system_info"]["kernel_backends"]["verify_backend"] == "hip"
+
+
+def test_manifest_has_the_reference_export_keys(tmp_path):
+    """MANIFEST.json of a results directory: the keys of the reference's exported runs (fixture data below is the key set and
+    nesting of docs/results/2025-10-30-T4-Phase3D-Run1-32tok-100iter-fp16/MANIFEST.json)."""
+    h = _harness()
+    args = SimpleNamespace(max_tokens=32, iterations=3, base_model="synthetic:llama-3.2-3b", draft_model="synthetic:llama-3.2-1b")
+    (tmp_path / "a.csv").write_text("x\n")
+    (tmp_path / "a.json").write_text("{}")
+    path = h.write_manifest(tmp_path, tmp_path / "a.csv", tmp_path / "a.json", args)
+    with open(path) as f:
+        man = json.load(f)
+    assert set(man) == {"export_created_at", "device", "dtype", "max_tokens", "iterations_per_k", "models", "artifacts", "source_dir"}
+    assert set(man["models"]) == {"base", "draft"} and set(man["artifacts"]) == {"summary_json", "summary_csv"}
+    assert man["artifacts"] == {"summary_json": "a.json", "summary_csv": "a.csv"} and man["iterations_per_k"] == 3
