@@ -13,27 +13,21 @@
 
 namespace sd {
 
-// Per-row adaptive K (sd_specdec_set_adaptive): launches of draft forward i >= 1 are in the captured step for every
-// i < K, but when no row proposes more than *k_active tokens the ones with i >= *k_active return at entry (one scalar
-// load; k_active == null, i.e. every other launch, costs a compare). Uniform: every wave takes the same branch.
 // scalar kernel arguments made live at one point (see pin_gemv_args, gemv_device.h): the s_loads are issued back to back
 #ifndef SD_NO_PIN_ARGS
 #define SD_PIN(...) asm volatile("" ::__VA_ARGS__)
 #else
 #define SD_PIN(...)
 #endif
-#ifndef SD_NO_SKIP
-#if defined(SD_SKIP_BRANCH)
-#define SD_SKIP_IF_INACTIVE(kptr, level)                                          \
-  do {                                                                            \
-    if ((kptr) != nullptr && *(kptr) <= (level)) return;                          \
-  } while (0)
-#else
+
+// Per-row adaptive K (sd_specdec_set_adaptive): launches of draft forward i >= 1 are in the captured step for every
+// i < K, but when no row proposes more than *k_active tokens the ones with i >= *k_active leave at once (one scalar
+// load; k_active == null, i.e. every other launch, costs a compare). Uniform: every wave takes the same path.
 // As ONE opaque statement (scalar compare, conditional scalar load, s_endpgm): written as C++ (`if (...) return;`) the
 // early exit splits the kernel's entry block, and everything the scheduler used to place under the latency of the
 // argument loads (lane / tile index arithmetic) then waits behind the branch — 0.5 % of the batch-1 step with the
-// check compiled in and never taken. Every wave of the launch takes the same path; nothing is in flight that matters
-// (the hardware drains a wave's outstanding loads at s_endpgm).
+// check compiled in and never taken. Nothing is in flight that matters (the hardware drains a wave's outstanding
+// loads at s_endpgm).
 #define SD_SKIP_IF_INACTIVE(kptr, level)                                          \
   do {                                                                            \
     int sd_skip_tmp_;                                                             \
@@ -50,11 +44,6 @@ namespace sd {
         : "s"(kptr), "s"(static_cast<int>(level))                                 \
         : "scc");                                                                 \
   } while (0)
-#endif
-#else
-#define SD_SKIP_IF_INACTIVE(kptr, level) do { } while (0)
-#endif
-
 
 // ---- error plumbing -------------------------------------------------------
 void set_error(const char* fmt, ...);

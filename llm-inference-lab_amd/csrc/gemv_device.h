@@ -99,13 +99,11 @@ __device__ __forceinline__ void epilogue(const GemvArgs& a, int p, int r0, int r
       // dense: "page" b of l_max positions; paged: the row's page for this position, P positions each
       size_t slab = static_cast<size_t>(b);
       int off = pos, plen = a.l_max;
-#ifndef SD_NO_PAGED_EPI
       if (a.block_table) {
         slab = static_cast<size_t>(a.block_table[b * (a.l_max >> a.page_shift) + (pos >> a.page_shift)]);
         plen = 1 << a.page_shift;
         off = pos & (plen - 1);
       }
-#endif
       if (is_k) {
         const int kvh = h - a.n_q_heads;
         uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + ((slab * a.n_kv_heads + kvh) * plen + off) * D + i;
