@@ -634,6 +634,7 @@ class SpeculativePipeline:
                         "throughput_tokens_per_sec": tot_tok / (total_ms / 1e3) if total_ms > 0 else 0.0,
                         "acceptance_rate": r.accepted / max(r.proposed, 1), "proposed": r.proposed, "accepted": r.accepted,
                         "steps": r.steps, "sequence": list(r.seq), "kv_append_enabled": True, "kv_append_backend": "hip",
+                        **({"k_trace": list(r.k_trace)} if r.k_trace else {}),
                         "batch_metrics": {"total_steps": sess.stats["steps"], "device_steps": sess.step, "resyncs": sess.stats["resyncs"],
                                           "void_row_steps": sess.stats["void_row_steps"], "k": sess.k}})
         return out

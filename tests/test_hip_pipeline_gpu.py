@@ -160,6 +160,24 @@ def test_per_row_adaptive_k_with_resyncs_and_admission():
     assert got[0]["batch_metrics"]["resyncs"] > 0, "the case no longer exercises the repair path"
 
 
+def test_per_row_adaptive_k_with_continuous_batching():
+    """generate_many over 2 slots with per-row adaptive K: a slot handed to a new prompt restarts that row's controller (host
+    mirror and device state) while the other row keeps its own; every result equals the prompt's own per-row-K run."""
+    drf, tgt = tiny_pair(flip_fraction=0.35)
+    params = {"initial_k": 3, "min_k": 1, "max_k": 4, "step_size": 1, "target_acceptance_rate": 0.6}
+    pipe = _pipe(drf, tgt, 4, controller="adaptive", controller_params=dict(params, per_row=True))
+    g = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(4, tgt.config.vocab, (int(n),), generator=g).tolist() for n in (6, 15, 4, 9, 12)]
+    got = pipe.generate_many(prompts, max_tokens=28, batch_size=2, do_sample=False)
+    eos = pipe.base_lm.get_tokenizer_info()["eos_token_id"]
+    for p, r in zip(prompts, got):
+        o = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=eos)
+        w = o.generate_batch([p], 28, per_row_k=params)[0]
+        assert r["generated_tokens"] == w["generated_tokens"]
+        assert (r["proposed"], r["accepted"]) == (w["proposed"], w["accepted"])
+        assert r["k_trace"] == o.k_trace[0]
+
+
 def test_loud_refusals():
     drf, tgt = tiny_pair()
     pipe = _pipe(drf, tgt, 2)
