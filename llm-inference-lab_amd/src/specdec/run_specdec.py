@@ -41,6 +41,8 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--min-k", type=int)
     ap.add_argument("--max-k", type=int)
     ap.add_argument("--target-acceptance", type=float)
+    ap.add_argument("--per-row-K", action="store_true",
+                    help="adaptive controller: every batch row its own K, moved on the device inside the captured step (not in the reference)")
     return ap.parse_args(argv)
 
 
@@ -54,6 +56,10 @@ def main(argv=None) -> int:
     if args.adaptive_K or args.controller == "adaptive":
         controller, cp = "adaptive", {k: v for k, v in (("min_k", args.min_k), ("max_k", args.max_k),
                                                        ("target_acceptance_rate", args.target_acceptance)) if v is not None}
+        if args.per_row_K:
+            cp["per_row"] = True
+            if args.max_k is not None and "initial_k" not in cp:
+                cp["initial_k"] = min(4, args.max_k)
     else:
         controller, cp = "fixed", {"k": args.K}
     try:
