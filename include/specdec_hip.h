@@ -289,6 +289,37 @@ int sd_model_hidden_rows(sd_model* m, int row0, int n, void* out, void* stream);
 int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, void* stream,
                         float* avg_usec, double* bytes_per_launch);
 
+/* ---- persistent forward (csrc/persist.hip) ---------------------------------
+ * Passes of <= sd_model_persist_tokens(m) tokens of a dense-KV Llama model with packed bf16 weights run as ONE launch
+ * (an LDS-DMA loader wave per CU streams the weights ahead of every dependency; activations cross CUs as tagged 8-byte
+ * granules) instead of five launches per layer. It replaces the same reference code as sd_model_forward does (the k-step
+ * draft loop, src/specdec/models/hf_wrappers.py:417-539). 0 = not available for this model / device (other
+ * architectures, fp8 or row-major weights, paged KV, a GPU without 256 CUs, SPECDEC_NO_PERSIST=1); the environment
+ * variable SPECDEC_PERSIST_MAX_T (read by sd_model_bind) lowers or raises the token limit (default 2, at most 8). */
+int sd_model_persist_tokens(const sd_model* m);
+
+/* Health word of the persistent launches of `m` since it was bound: 0 = every launch ran to completion. Every wait
+ * inside the launch is bounded (50 ms); a workgroup that gives up ORs a reason into this word (1 loader blocked, 2 weights
+ * never landed, 4 / 8 intra-workgroup hand-over, 16 granules of another CU never arrived, 32 attention hand-over) and
+ * leaves, and the pass's outputs are then invalid. Synchronises `stream` (one 4-byte copy to the host). The step loop
+ * also carries the word of its models in every step record (sd_specdec_record). */
+int sd_model_engine_status(sd_model* m, uint32_t* status_out, void* stream);
+
+/* Rows [row0, row0+n) of one of the workspace buffers the last pass left behind (bf16, asynchronous copy on `stream`):
+ * which = 0 residual stream [d_model] (= sd_model_hidden_rows), 1 q after RoPE [Hq*D], 2 attention rows [Hq*D],
+ * 3 MLP activation [d_ff]; all of the LAST layer. For stage-by-stage checks of the persistent launch against the
+ * launch-per-operator forward. */
+int sd_model_debug_rows(sd_model* m, int which, int row0, int n, void* out, void* stream);
+
+/* Measurement hook: `iters` whole forwards of one row of M tokens (token id 0, positions 0..M-1 of cache row 0, which
+ * they overwrite) between two HIP events on `stream`; returns the average duration of a forward and the bytes of weights
+ * it streams. skip_head = 1 leaves the lm_head out. timeline (optional, host memory, `timeline_cap` uint64): in-kernel
+ * 100 MHz stamps of ONE further persistent forward, [256 workgroups][12 * n_ops + 4] (per op: gather start, input staged,
+ * MFMA + epilogue done, attention done, third consumer's start and MFMA end, leader's MFMA end, loader done issuing the
+ * op; then s_memrealtime / s_memtime at the workgroup's start and end: the shader clock it ran at); allocates and frees a device buffer and synchronises. */
+int sd_model_probe_forward(sd_model* m, int M, int iters, int skip_head, void* stream, float* avg_usec,
+                           double* bytes_per_forward, unsigned long long* timeline, size_t timeline_cap);
+
 /* ---- the step loop ------------------------------------------------------- */
 typedef struct sd_specdec sd_specdec;
 

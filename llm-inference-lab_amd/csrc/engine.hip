@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "persist.h"
 
 struct sd_model {
   sd_model_config cfg;
@@ -55,6 +56,13 @@ struct sd_model {
   int is_packed() const { return packed.empty() ? 0 : 1; }
   int w8() const { return scales.empty() ? 0 : 1; }
   const float* scale(int index) const { return scales.empty() ? nullptr : scales[index]; }
+  // persistent forward (csrc/persist.hip): passes of <= persist_t tokens run as ONE launch
+  int persist_t = 0;                       // 0 = not available for this model / device
+  sd::PersistOp* p_ops = nullptr;          // device: 4 per layer + lm_head, stream order
+  unsigned long long* p_gran = nullptr;    // granule buffers, two parities
+  unsigned p_gran_parity = 0;
+  unsigned* p_sync = nullptr;              // [0] launch counter, [1] status
+  unsigned long long* p_debug = nullptr;   // optional timeline (sd_model_probe_persist)
 };
 
 namespace sd {
@@ -72,6 +80,7 @@ static size_t workspace_bytes(const sd_model_config& c) {
   n += align_up(T * kMaxPartials * 4, 256) * 2;
   n += align_up(attention_split_ws_bytes(c.head_dim), 256);
   n += align_up(sizeof(float) * 2 * kStatPlane, 256);
+  n += align_up(persist_workspace_bytes(c), 256);
   return n + 256;
 }
 
@@ -85,6 +94,52 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   const int d = c.d_model, Hq = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, ff = c.d_ff;
   const bool llama = (c.arch == SD_ARCH_LLAMA);
   const int pro = llama ? PRO_RMSNORM : PRO_LAYERNORM;
+
+  // ---- the whole pass as ONE persistent launch (csrc/persist.hip): small passes of a dense-KV Llama model
+  if (m->persist_t > 0 && T <= m->persist_t && Mc <= 8 && !m->block_table && Bc * Hq <= kPersistCUs) {
+    PersistArgs pa{};
+    pa.ops = m->p_ops;
+    pa.n_ops = 4 * c.n_layers + (skip_head ? 0 : 1);
+    pa.d_model = d; pa.n_q_heads = Hq; pa.n_kv_heads = Hkv; pa.head_dim = D; pa.d_ff = ff; pa.vocab = c.vocab;
+    pa.n_layers = c.n_layers; pa.max_pos = c.max_pos;
+    pa.norm_eps = c.norm_eps;
+    pa.attn_scale = 1.0f / sqrtf(static_cast<float>(D));
+    pa.tok_emb = c.tok_emb;
+    pa.rope_cos = c.rope_cos;
+    pa.rope_sin = c.rope_sin;
+    pa.tokens = tokens + static_cast<size_t>(b0) * tok_stride;
+    pa.tok_stride = tok_stride;
+    pa.pos_base = pos_base + b0;
+    pa.pos_off = pos_off;
+    pa.B = Bc;
+    pa.M = Mc;
+    const size_t row_off = static_cast<size_t>(row0 + b0) * Hkv * m->Lmax * D;
+    pa.k_cache = m->k_cache + row_off;
+    pa.v_cache = m->v_cache + row_off;
+    pa.layer_kv = static_cast<size_t>(m->B) * Hkv * m->Lmax * D;
+    pa.l_max = m->Lmax;
+    pa.logits = logits_out;
+    pa.logits_dtype = logits_dtype;
+    pa.logits_stride = logits_stride;
+    pa.part_val = m->part_val;
+    pa.part_idx = m->part_idx;
+    pa.x = m->x; pa.q = m->q; pa.attn = m->attn; pa.act = m->act;
+    pa.gran = m->p_gran;
+    pa.gran_parity = m->p_gran_parity;
+    pa.sync = m->p_sync;
+    pa.skip_k = m->skip_k;
+    pa.skip_i = m->skip_i;
+    pa.debug_ts = m->p_debug;
+    if (int rc = launch_persist_forward(pa, st)) return rc;
+    if (skip_head) return 0;
+    m->head_grid = kPersistCUs;
+    if (ids_out) {
+      if (int rc = launch_argmax_finalize(m->part_val, m->part_idx, T, m->head_grid, Mc, ids_stride,
+                                          ids_out + static_cast<size_t>(b0) * ids_stride, st, m->skip_k, m->skip_i))
+        return rc;
+    }
+    return 0;
+  }
 
   EmbedArgs e{};
   e.tok_emb = c.tok_emb;
@@ -495,6 +550,54 @@ static int carve_workspace(sd_model* m, void* workspace) {
   p += align_up(sizeof(float) * 2 * kStatPlane, 256);
   SD_HIP_CHECK(hipMemset(m->attn_cnt, 0, kAttnSplitSlots * sizeof(unsigned)));
   m->probe_pos = reinterpret_cast<int32_t*>(m->attn_cnt);   // a zero word (the counters rest at zero between launches)
+  // ---- persistent forward: sync words, op table, granule buffers (all zero: tag 0 is never a valid tag)
+  {
+    char* pp = p;
+    const size_t pbytes = persist_workspace_bytes(c);
+    SD_HIP_CHECK(hipMemset(pp, 0, pbytes));
+    m->p_sync = reinterpret_cast<unsigned*>(pp);
+    pp += 256;
+    m->p_ops = reinterpret_cast<PersistOp*>(pp);
+    pp += align_up(static_cast<size_t>(4 * c.n_layers + 1) * sizeof(PersistOp), 256);
+    m->p_gran = reinterpret_cast<unsigned long long*>(pp);
+    m->p_gran_parity = static_cast<unsigned>((pbytes - 256 - align_up(static_cast<size_t>(4 * c.n_layers + 1) * sizeof(PersistOp), 256)) / 16);
+    m->persist_t = 0;
+    int dev = 0;
+    hipDeviceProp_t prop{};
+    SD_HIP_CHECK(hipGetDevice(&dev));
+    SD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (persist_model_ok(c, m->is_packed() != 0, m->w8() != 0, prop.multiProcessorCount)) {
+      const int HqD = c.n_heads * c.head_dim;
+      std::vector<PersistOp> ops;
+      auto add = [&](int index, const void* norm_w, int n_pairs, int K, int kind, int layer) {
+        const GemvGeom q = gemv_geometry(n_pairs, K);
+        PersistOp o{};
+        o.W = m->packed[index];
+        o.norm_w = norm_w;
+        o.pair_bytes = static_cast<unsigned>(4 * K);
+        o.n_pairs = n_pairs;
+        o.ppw = q.ppw;
+        o.tile_pairs = q.tile_pairs;
+        o.K = K;
+        o.kind = kind;
+        o.layer = layer;
+        ops.push_back(o);
+      };
+      for (int l = 0; l < c.n_layers; ++l) {
+        const sd_layer_weights& w = m->layers[l];
+        add(4 * l + 0, w.attn_norm_w, (c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, c.d_model, POP_QKV, l);
+        add(4 * l + 1, nullptr, c.d_model / 2, HqD, POP_OUT, l);
+        add(4 * l + 2, w.mlp_norm_w, c.d_ff, c.d_model, POP_GATEUP, l);
+        add(4 * l + 3, nullptr, c.d_model / 2, c.d_ff, POP_DOWN, l);
+      }
+      add(4 * c.n_layers, c.final_norm_w, (c.vocab + 1) / 2, c.d_model, POP_HEAD, c.n_layers);
+      SD_HIP_CHECK(hipMemcpy(m->p_ops, ops.data(), ops.size() * sizeof(PersistOp), hipMemcpyHostToDevice));
+      int cap = persist_max_tokens(c);
+      const char* env = getenv("SPECDEC_PERSIST_MAX_T");   // tokens per pass the persistent launch takes (0 = off)
+      const int want = env ? atoi(env) : 2;
+      m->persist_t = cap < want ? cap : want;
+    }
+  }
   return 0;
 }
 
@@ -638,6 +741,86 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
       }
       fprintf(stderr, "  %-10s %7.2f %7.2f %7.2f\n", names[s], mn, sum / (n ? n : 1), mx);
     }
+  }
+  return 0;
+}
+
+extern "C" int sd_model_persist_tokens(const sd_model* m) { return m ? m->persist_t : 0; }
+
+extern "C" int sd_model_engine_status(sd_model* m, uint32_t* status_out, void* stream) {
+  clear_error();
+  SD_REQUIRE(m && status_out, "engine_status: NULL argument");
+  *status_out = 0;
+  if (!m->p_sync) return 0;
+  SD_HIP_CHECK(hipMemcpyAsync(status_out, m->p_sync + 1, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  SD_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int sd_model_debug_rows(sd_model* m, int which, int row0, int n, void* out, void* stream) {
+  clear_error();
+  SD_REQUIRE(m && m->x && out, "debug_rows: NULL argument / model not bound");
+  SD_REQUIRE(row0 >= 0 && n >= 1 && row0 + n <= kSkinnyMaxT, "debug_rows: rows [%d,%d) outside the %d rows of a pass", row0, row0 + n, kSkinnyMaxT);
+  const sd_model_config& c = m->cfg;
+  const uint16_t* src = nullptr;
+  size_t w = 0;
+  switch (which) {
+    case 0: src = m->x; w = c.d_model; break;
+    case 1: src = m->q; w = static_cast<size_t>(c.n_heads) * c.head_dim; break;
+    case 2: src = m->attn; w = static_cast<size_t>(c.n_heads) * c.head_dim; break;
+    case 3: src = m->act; w = c.d_ff; break;
+    default: SD_REQUIRE(false, "debug_rows: which=%d (0 x, 1 q, 2 attn, 3 act)", which);
+  }
+  SD_HIP_CHECK(hipMemcpyAsync(out, src + static_cast<size_t>(row0) * w, static_cast<size_t>(n) * w * 2, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int sd_model_probe_forward(sd_model* m, int M, int iters, int skip_head, void* stream, float* avg_usec,
+                                      double* bytes_per_forward, unsigned long long* timeline, size_t timeline_cap) {
+  clear_error();
+  SD_REQUIRE(m && m->x && avg_usec && bytes_per_forward, "probe_forward: NULL argument / model not bound");
+  SD_REQUIRE(M >= 1 && M <= kSkinnyMaxT && iters >= 1, "probe_forward: M=%d iters=%d", M, iters);
+  SD_REQUIRE(!m->block_table, "probe_forward: dense KV only");
+  const sd_model_config& c = m->cfg;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int32_t* zeros = reinterpret_cast<const int32_t*>(m->attn_cnt);   // kAttnSplitSlots zero words: token ids and the position base
+  auto fwd = [&]() { return model_forward(m, zeros, M, zeros, 0, 0, 1, M, nullptr, M, nullptr, SD_BF16, skip_head, st); };
+  hipEvent_t e0, e1;
+  SD_HIP_CHECK(hipEventCreate(&e0));
+  SD_HIP_CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i)
+    if (int rc = fwd()) return rc;
+  SD_HIP_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i)
+    if (int rc = fwd()) return rc;
+  SD_HIP_CHECK(hipEventRecord(e1, st));
+  SD_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_usec = ms * 1000.0f / iters;
+  const bool llama = (c.arch == SD_ARCH_LLAMA);
+  double per_layer = 2.0 * ((c.n_heads + 2.0 * c.n_kv_heads) * c.head_dim * c.d_model + static_cast<double>(c.d_model) * c.n_heads * c.head_dim +
+                            (llama ? 3.0 : 2.0) * c.d_ff * c.d_model);
+  double bytes = per_layer * c.n_layers + (skip_head ? 0.0 : 2.0 * c.vocab * c.d_model);
+  if (m->w8()) bytes *= 0.5;
+  *bytes_per_forward = bytes;
+  if (timeline && m->persist_t >= M) {
+    const size_t n_ops = static_cast<size_t>(4 * c.n_layers + (skip_head ? 0 : 1));
+    const size_t words = static_cast<size_t>(kPersistCUs) * (12 * n_ops + 4);
+    SD_REQUIRE(timeline_cap >= words, "probe_forward: timeline needs %zu words", words);
+    unsigned long long* dbg = nullptr;
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), words * 8));
+    SD_HIP_CHECK(hipMemsetAsync(dbg, 0, words * 8, st));
+    m->p_debug = dbg;
+    const int rc = fwd();
+    m->p_debug = nullptr;
+    if (rc) { (void)hipFree(dbg); return rc; }
+    SD_HIP_CHECK(hipStreamSynchronize(st));
+    SD_HIP_CHECK(hipMemcpy(timeline, dbg, words * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
   }
   return 0;
 }

@@ -234,6 +234,46 @@ class HipModel:
         _abi.check(rc, "sd_model_probe_gemv")
         return float(usec.value), float(nbytes.value)
 
+    @property
+    def persist_tokens(self) -> int:
+        """Tokens per pass that run as ONE persistent launch (sd_model_persist_tokens); 0 = launch-per-operator only."""
+        return int(self.lib.sd_model_persist_tokens(self.handle))
+
+    def engine_status(self, stream: Optional[torch.cuda.Stream] = None) -> int:
+        """0 = every persistent launch of this model completed (sd_model_engine_status; synchronises the stream)."""
+        st = ctypes.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_model_engine_status(self.handle, ctypes.byref(st), _stream(stream, self.device)), "sd_model_engine_status")
+        return int(st.value)
+
+    DEBUG_X, DEBUG_Q, DEBUG_ATTN, DEBUG_ACT = 0, 1, 2, 3
+
+    def debug_rows(self, which: int, n: int, row0: int = 0, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        """bf16 [n][width]: rows of a workspace buffer of the last pass, last layer (sd_model_debug_rows)."""
+        c = self.cfg
+        width = {0: c.d_model, 1: c.n_heads * c.head_dim, 2: c.n_heads * c.head_dim, 3: c.d_ff}[int(which)]
+        out = torch.empty((n, width), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_model_debug_rows(self.handle, int(which), int(row0), int(n), out.data_ptr(), _stream(stream, self.device)),
+                       "sd_model_debug_rows")
+        return out
+
+    def probe_forward(self, M: int = 1, iters: int = 50, skip_head: bool = False, timeline: bool = False,
+                      stream: Optional[torch.cuda.Stream] = None):
+        """(average microseconds per forward of M tokens, bytes of weights per forward, timeline or None): sd_model_probe_forward.
+        timeline: uint64 [256][12 * n_ops + 4] stamps (100 MHz) of one persistent forward — per op: gather start, input staged,
+        op done, attention done, third consumer start, its MFMA end, leader MFMA end, loader done issuing; then (realtime,
+        shader clock) at start and end."""
+        usec, nbytes = ctypes.c_float(0), ctypes.c_double(0)
+        n_ops = 4 * self.cfg.n_layers + (0 if skip_head else 1)
+        tl = np.zeros(256 * (12 * n_ops + 4), dtype=np.uint64) if timeline else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.sd_model_probe_forward(self.handle, int(M), int(iters), 1 if skip_head else 0, _stream(stream, self.device),
+                                                 ctypes.byref(usec), ctypes.byref(nbytes),
+                                                 tl.ctypes.data if tl is not None else None, tl.size if tl is not None else 0)
+        _abi.check(rc, "sd_model_probe_forward")
+        return float(usec.value), float(nbytes.value), tl
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.sd_model_destroy(self.handle)
