@@ -311,13 +311,13 @@ int sd_model_engine_status(sd_model* m, uint32_t* status_out, void* stream);
  * launch-per-operator forward. */
 int sd_model_debug_rows(sd_model* m, int which, int row0, int n, void* out, void* stream);
 
-/* Measurement hook: `iters` whole forwards of one row of M tokens (token id 0, positions 0..M-1 of cache row 0, which
- * they overwrite) between two HIP events on `stream`; returns the average duration of a forward and the bytes of weights
+/* Measurement hook: `iters` whole forwards of one row of M tokens (token id 0, positions pos0..pos0+M-1 of cache row 0,
+ * which they overwrite; the attention reads the pos0 positions below, whatever the cache holds) between two HIP events on `stream`; returns the average duration of a forward and the bytes of weights
  * it streams. skip_head = 1 leaves the lm_head out. timeline (optional, host memory, `timeline_cap` uint64): in-kernel
  * 100 MHz stamps of ONE further persistent forward, [256 workgroups][12 * n_ops + 4] (per op: gather start, input staged,
  * MFMA + epilogue done, attention done, third consumer's start and MFMA end, leader's MFMA end, loader done issuing the
  * op; then s_memrealtime / s_memtime at the workgroup's start and end: the shader clock it ran at); allocates and frees a device buffer and synchronises. */
-int sd_model_probe_forward(sd_model* m, int M, int iters, int skip_head, void* stream, float* avg_usec,
+int sd_model_probe_forward(sd_model* m, int M, int pos0, int iters, int skip_head, void* stream, float* avg_usec,
                            double* bytes_per_forward, unsigned long long* timeline, size_t timeline_cap);
 
 /* ---- the step loop ------------------------------------------------------- */

@@ -776,16 +776,17 @@ extern "C" int sd_model_debug_rows(sd_model* m, int which, int row0, int n, void
   return 0;
 }
 
-extern "C" int sd_model_probe_forward(sd_model* m, int M, int iters, int skip_head, void* stream, float* avg_usec,
+extern "C" int sd_model_probe_forward(sd_model* m, int M, int pos0, int iters, int skip_head, void* stream, float* avg_usec,
                                       double* bytes_per_forward, unsigned long long* timeline, size_t timeline_cap) {
   clear_error();
   SD_REQUIRE(m && m->x && avg_usec && bytes_per_forward, "probe_forward: NULL argument / model not bound");
   SD_REQUIRE(M >= 1 && M <= kSkinnyMaxT && iters >= 1, "probe_forward: M=%d iters=%d", M, iters);
+  SD_REQUIRE(pos0 >= 0 && pos0 + M <= m->Lmax, "probe_forward: positions [%d, %d) outside the cache rows (%d)", pos0, pos0 + M, m->Lmax);
   SD_REQUIRE(!m->block_table, "probe_forward: dense KV only");
   const sd_model_config& c = m->cfg;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int32_t* zeros = reinterpret_cast<const int32_t*>(m->attn_cnt);   // kAttnSplitSlots zero words: token ids and the position base
-  auto fwd = [&]() { return model_forward(m, zeros, M, zeros, 0, 0, 1, M, nullptr, M, nullptr, SD_BF16, skip_head, st); };
+  auto fwd = [&]() { return model_forward(m, zeros, M, zeros, pos0, 0, 1, M, nullptr, M, nullptr, SD_BF16, skip_head, st); };
   hipEvent_t e0, e1;
   SD_HIP_CHECK(hipEventCreate(&e0));
   SD_HIP_CHECK(hipEventCreate(&e1));

@@ -42,6 +42,32 @@
 #include "gemv_device.h"
 #include "persist.h"
 
+// ---- tuning switches (compile time; defaults = what same-box A/B runs of profiles/tools/ab_persist.sh kept) -------------
+#ifndef SD_P_CHUNK
+#define SD_P_CHUNK 16      // MFMAs per chunk: 8 -> +14 us per 1B forward, 32 -> +50 us
+#endif
+#ifndef SD_P_PIPEPOLL
+#define SD_P_PIPEPOLL 0    // two sweep passes in flight: +27 us per forward (polling traffic)
+#endif
+#ifndef SD_P_BACKOFF
+#define SD_P_BACKOFF 2     // s_sleep units after an incomplete sweep pass (0 / 2 / 8: no difference)
+#endif
+#ifndef SD_P_GWAIT
+#define SD_P_GWAIT 0       // first sweep pass only after this CU's own leader has published: +2 us per forward
+#endif
+#ifndef SD_P_SPLIT
+#define SD_P_SPLIT 2048    // rows wider than this many granules are swept by two waves (off: +15 us per forward)
+#endif
+#ifndef SD_P_THIN
+#define SD_P_THIN 1        // while this CU's gatherer sweeps the loader keeps 1 slot in flight (-10 us per forward); 2: none
+#endif
+#ifndef SD_P_THINATT
+#define SD_P_THINATT 1     // the same while an attention CU sweeps q / k / v (-4 us per forward)
+#endif
+#ifndef SD_P_INFLIGHT
+#define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
+#endif
+
 namespace sd {
 namespace {
 
@@ -62,14 +88,19 @@ struct PCtl {   // LDS control words (all written with relaxed workgroup-scope a
   unsigned a_seq;        // attention units whose q / new k / new v are staged
   unsigned a_done[3];    // attention partials written
   unsigned a_merged;     // attention units merged
+  unsigned g2_seq;       // ops whose second half of the input rows the third consumer has staged (wide rows only)
+  unsigned gathering;    // the gatherer is sweeping: the loader keeps one slot in flight (its bursts queue in front of the sweep's loads)
 };
 
 typedef const PersistOp __attribute__((address_space(4)))* cops_t;   // uniform reads through the scalar cache
 
+// (control words are wave-uniform by construction: readfirstlane keeps everything derived from them — loop bounds, ring
+//  positions, branches — on the scalar unit; left as a per-lane value, every wait loop and the whole chunk loop of the
+//  consumers became exec-masked vector control flow, ~110 instructions per chunk for a wave that issues one per ~5 cycles)
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) {
   const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
-  return v;
+  return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
 __device__ __forceinline__ void lds_st(unsigned* p, unsigned v) {
   asm volatile("" ::: "memory");
@@ -91,23 +122,27 @@ struct PCtx {
   cops_t ops;
 };
 
-__device__ __forceinline__ bool expired(const PCtx& c) {
-  return lds_ld(&c.ctl->abort_) != 0u || static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - c.t_start) > kTimeoutTicks;
+// (cold paths, out of line: they are referenced from every wait loop of a kernel that is one big inlined function)
+__device__ __attribute__((noinline)) bool expired_slow(const unsigned* abort_word, unsigned long long t_start) {
+  return lds_ld(abort_word) != 0u || static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - t_start) > kTimeoutTicks;
 }
-__device__ __forceinline__ void give_up(const PCtx& c, unsigned code) {
-  lds_st(&c.ctl->abort_, 1u);
-  if (c.lane == 0) atomicOr(c.a->sync + 1, code);
+__device__ __forceinline__ bool expired(const PCtx& c) { return expired_slow(&c.ctl->abort_, c.t_start); }
+__device__ __attribute__((noinline)) void give_up_slow(unsigned* abort_word, unsigned* status, unsigned code, int lane) {
+  lds_st(abort_word, 1u);
+  if (lane == 0) atomicOr(status, code);
 }
+__device__ __forceinline__ void give_up(const PCtx& c, unsigned code) { give_up_slow(&c.ctl->abort_, c.a->sync + 1, code, c.lane); }
 __device__ __forceinline__ void stamp(const PCtx& c, int slot) {
   if (c.a->debug_ts && c.lane == 0) c.a->debug_ts[static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
 // wait until an LDS word reaches `need`
+// (no s_sleep: every wave of the workgroup owns its SIMD, so a spinning wave costs the others nothing but LDS read slots,
+//  and each hop of the intra-CU hand-overs — input staged, partial in, tile folded — sits on the layer's critical path)
 template <int NAP>
 __device__ __forceinline__ bool wait_word(const PCtx& c, const unsigned* p, unsigned need, unsigned code) {
   for (unsigned spins = 1; lds_ld(p) < need; ++spins) {
-    __builtin_amdgcn_s_sleep(NAP);
-    if ((spins & 255u) == 0u && expired(c)) { give_up(c, code); return false; }
+    if ((spins & 1023u) == 0u && expired(c)) { give_up(c, code); return false; }
   }
   return true;
 }
@@ -177,6 +212,17 @@ __device__ __forceinline__ void loader_role(const PCtx& c) {
       __builtin_amdgcn_s_sleep(2);
       if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_LOADER); return; }
     }
+    if (SD_P_THIN == 2) {
+      for (unsigned spins = 1; lds_ld(&c.ctl->gathering); ++spins) {
+        if (pub != issued) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          pub = issued;
+          lds_st(&c.ctl->landed, pub);
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_LOADER); return; }
+      }
+    }
     unsigned n = 0;
     if (left > 16 || (left == 16 && tail == kPiece)) {
       // a whole slot of full pieces inside one segment: the tight path (the loader must issue a slot in well under its
@@ -206,11 +252,21 @@ __device__ __forceinline__ void loader_role(const PCtx& c) {
       }
     }
     issued += n;
-    if (n == 16 && left) {
+    if (SD_P_THIN && lds_ld(&c.ctl->gathering)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pub = issued;
+      lds_st(&c.ctl->landed, pub);
+    } else if (n == 16 && left) {
       // every slot before this one was a full one: all but the 32 newest instructions have landed
+#if SD_P_INFLIGHT == 3
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      if (issued >= 32u && issued - 32u > pub) {
-        pub = issued - 32u;
+      constexpr unsigned kBehind = 32u;
+#else
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      constexpr unsigned kBehind = 16u;
+#endif
+      if (issued >= kBehind && issued - kBehind > pub) {
+        pub = issued - kBehind;
         lds_st(&c.ctl->landed, pub);
       }
     } else {
@@ -253,79 +309,127 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
   __hip_atomic_store(g, (static_cast<unsigned long long>(tag) << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// fused epilogue of one tile (leader): lane = (token t, pair slot jp); y0 / y1 = the two rows of the pair
-__device__ __forceinline__ void leader_epilogue(const PCtx& c, const OpView& o, int tile, int np, const float* part, const LeadLane& L,
-                                                ConsState& st) {
+// ---- fused epilogue of one tile (leader): lane = (token t, pair slot jp); y0 / y1 = the two rows of the pair ---------
+// Split in two: everything that does not depend on the sums (addresses, RoPE factors, the old residual) is computed BEFORE
+// the leader waits for the partial tiles — a wave alone on its SIMD runs ~5 cycles per instruction, and the epilogue sits
+// on the layer's critical path at every op.
+struct EpiPrep {
+  bool valid;
+  int p;
+  unsigned long long* gran;   // granule this lane publishes
+  unsigned tag;
+  // QKV
+  bool rope;
+  float2 cs;
+  uint16_t* d0;               // q row / K row / V^T column of the pair's first element (null: nothing to store)
+  size_t d1;                  // element offset of the pair's second element from d0
+  // residual ops
+  unsigned* res;
+  unsigned old;
+  unsigned* xtap;
+  // gate/up
+  unsigned* acttap;
+};
+
+__device__ __forceinline__ EpiPrep epilogue_prep(const PCtx& c, const OpView& o, int tile, int np, const LeadLane& L) {
   const PersistArgs& a = *c.a;
-  const bool valid = L.tok_ok && L.jp < np;
-  float y0 = 0.f, y1 = 0.f;
-  if (valid) {
-#pragma unroll
-    for (int w = 0; w < 3; ++w) {
-      y0 += part[(w * 16 + L.jp) * kPartT + L.t];
-      y1 += part[(w * 16 + L.jp + 8) * kPartT + L.t];
-    }
-  }
-  const int p = o.p_lo + tile * o.tile_pairs + L.jp;
+  EpiPrep e{};
+  e.valid = L.tok_ok && L.jp < np;
+  e.p = o.p_lo + tile * o.tile_pairs + L.jp;
+  const int p = e.valid ? e.p : o.p_lo;   // keep the address arithmetic of idle lanes in range
   if (o.kind == POP_QKV) {
-    if (valid) {
-      const int half = a.head_dim >> 1;
-      const int h = p / half, i = p - h * half;
-      float o0 = y0, o1 = y1;
-      if (h < a.n_q_heads + a.n_kv_heads && L.pos >= 0 && L.pos < a.max_pos) {
-        const float2 cs = reinterpret_cast<const float2*>(c.smem + a.lds_rope)[tile * 64 + c.lane];
-        o0 = y0 * cs.x - y1 * cs.y;
-        o1 = y1 * cs.x + y0 * cs.y;
-      }
-      const uint16_t u0 = float_to_bf16_bits(o0), u1 = float_to_bf16_bits(o1);
-      store_granule(granule_ptr(a, o.layer, PE_QKV, static_cast<unsigned>(L.t) * o.n_pairs + p), edge_tag(c, o.layer, PE_QKV),
-                    static_cast<unsigned>(u0) | (static_cast<unsigned>(u1) << 16));
-      const int Dh = a.head_dim;
-      if (h < a.n_q_heads) {
-        uint16_t* q = static_cast<uint16_t*>(a.q) + static_cast<size_t>(L.t) * a.n_q_heads * Dh + h * Dh + i;
-        q[0] = u0;
-        q[half] = u1;
-      } else if (L.pos >= 0 && L.pos < a.l_max) {
-        // in-place KV append, as epilogue<EPI_QKV_ROPE> (gemv_device.h): K rows [l_max][D], V transposed [D][l_max]
-        const size_t lbase = static_cast<size_t>(o.layer) * a.layer_kv;
-        if (h < a.n_q_heads + a.n_kv_heads) {
-          const int kvh = h - a.n_q_heads;
-          uint16_t* dst = static_cast<uint16_t*>(a.k_cache) + lbase + ((static_cast<size_t>(L.b) * a.n_kv_heads + kvh) * a.l_max + L.pos) * Dh + i;
-          dst[0] = u0;
-          dst[half] = u1;
-        } else {
-          const int kvh = h - a.n_q_heads - a.n_kv_heads;
-          uint16_t* dst = static_cast<uint16_t*>(a.v_cache) + lbase + ((static_cast<size_t>(L.b) * a.n_kv_heads + kvh) * Dh + i) * a.l_max + L.pos;
-          dst[0] = u0;
-          dst[static_cast<size_t>(half) * a.l_max] = u1;
-        }
+    const int half = a.head_dim >> 1, Dh = a.head_dim;
+    const int h = p / half, i = p - h * half;
+    e.rope = h < a.n_q_heads + a.n_kv_heads && L.pos >= 0 && L.pos < a.max_pos;
+    e.cs = reinterpret_cast<const float2*>(c.smem + a.lds_rope)[tile * 64 + c.lane];
+    e.gran = granule_ptr(a, o.layer, PE_QKV, static_cast<unsigned>(L.t) * o.n_pairs + p);
+    e.tag = edge_tag(c, o.layer, PE_QKV);
+    if (h < a.n_q_heads) {
+      e.d0 = static_cast<uint16_t*>(a.q) + static_cast<size_t>(L.t) * a.n_q_heads * Dh + h * Dh + i;
+      e.d1 = half;
+    } else if (L.pos >= 0 && L.pos < a.l_max) {
+      // in-place KV append, as epilogue<EPI_QKV_ROPE> (gemv_device.h): K rows [l_max][D], V transposed [D][l_max]
+      const size_t lbase = static_cast<size_t>(o.layer) * a.layer_kv;
+      if (h < a.n_q_heads + a.n_kv_heads) {
+        const int kvh = h - a.n_q_heads;
+        e.d0 = static_cast<uint16_t*>(a.k_cache) + lbase + ((static_cast<size_t>(L.b) * a.n_kv_heads + kvh) * a.l_max + L.pos) * Dh + i;
+        e.d1 = half;
+      } else {
+        const int kvh = h - a.n_q_heads - a.n_kv_heads;
+        e.d0 = static_cast<uint16_t*>(a.v_cache) + lbase + ((static_cast<size_t>(L.b) * a.n_kv_heads + kvh) * Dh + i) * a.l_max + L.pos;
+        e.d1 = static_cast<size_t>(half) * a.l_max;
       }
     }
   } else if (o.kind == POP_OUT || o.kind == POP_DOWN) {
-    if (valid) {
-      unsigned* res = reinterpret_cast<unsigned*>(c.smem + a.lds_resid) + L.t * a.resid_ppw + tile * o.tile_pairs + L.jp;
-      const unsigned old = *res;
-      const float n0 = __uint_as_float(old << 16) + y0;
-      const float n1 = __uint_as_float(old & 0xffff0000u) + y1;
+    e.res = reinterpret_cast<unsigned*>(c.smem + a.lds_resid) + (e.valid ? L.t * a.resid_ppw + tile * o.tile_pairs + L.jp : 0u);
+    e.old = *e.res;
+    const int edge = (o.kind == POP_OUT) ? PE_X2 : PE_X;
+    const int lay = (o.kind == POP_OUT) ? o.layer : o.layer + 1;   // the down-projection feeds the NEXT layer (or the head)
+    e.gran = granule_ptr(a, lay, edge, static_cast<unsigned>(L.t) * o.n_pairs + p);
+    e.tag = edge_tag(c, lay, edge);
+    e.xtap = reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.x) + static_cast<size_t>(L.t) * a.d_model) + p;
+  } else if (o.kind == POP_GATEUP) {
+    e.gran = granule_ptr(a, o.layer, PE_ACT, static_cast<unsigned>(L.t) * (o.n_pairs >> 1) + (p >> 1));
+    e.tag = edge_tag(c, o.layer, PE_ACT);
+    e.acttap = reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.act) + static_cast<size_t>(L.t) * a.d_ff) + (p >> 1);
+  }
+  return e;
+}
+
+// dbl: the tile was multiplied two steps at a time (consume_op): real row r of the tile = MFMA rows r (even k groups, token
+// column 2 t, stored as partial row r) + r + 8 (odd k groups, column 2 t + 1, stored as partial row r + 8)
+template <int W_FIRST, bool DBL>
+__device__ __forceinline__ void epilogue_finish(const PCtx& c, const OpView& o, const EpiPrep& e, const float* part, const LeadLane& L, ConsState& st) {
+  const PersistArgs& a = *c.a;
+  float y0 = 0.f, y1 = 0.f;
+  if (e.valid) {
+#pragma unroll
+    for (int w = W_FIRST; w < 3; ++w) {   // fixed order: deterministic
+      const float* pw = part + w * 16 * kPartT + L.t;
+      if constexpr (DBL) {
+        y0 += pw[L.jp * kPartT] + pw[(L.jp + 8) * kPartT];
+        y1 += pw[(L.jp + 4) * kPartT] + pw[(L.jp + 12) * kPartT];
+      } else {
+        y0 += pw[L.jp * kPartT];
+        y1 += pw[(L.jp + 8) * kPartT];
+      }
+    }
+  }
+  if (o.kind == POP_QKV) {
+    if (e.valid) {
+      float o0 = y0, o1 = y1;
+      if (e.rope) {
+        o0 = y0 * e.cs.x - y1 * e.cs.y;
+        o1 = y1 * e.cs.x + y0 * e.cs.y;
+      }
+      const uint16_t u0 = float_to_bf16_bits(o0), u1 = float_to_bf16_bits(o1);
+      store_granule(e.gran, e.tag, static_cast<unsigned>(u0) | (static_cast<unsigned>(u1) << 16));
+      if (e.d0) {
+        e.d0[0] = u0;
+        e.d0[e.d1] = u1;
+      }
+    }
+  } else if (o.kind == POP_OUT || o.kind == POP_DOWN) {
+    if (e.valid) {
+      const float n0 = __uint_as_float(e.old << 16) + y0;
+      const float n1 = __uint_as_float(e.old & 0xffff0000u) + y1;
       const unsigned nv = static_cast<unsigned>(float_to_bf16_bits(n0)) | (static_cast<unsigned>(float_to_bf16_bits(n1)) << 16);
-      *res = nv;
-      const int edge = (o.kind == POP_OUT) ? PE_X2 : PE_X;
-      const int lay = (o.kind == POP_OUT) ? o.layer : o.layer + 1;   // the down-projection feeds the NEXT layer (or the head)
-      store_granule(granule_ptr(a, lay, edge, static_cast<unsigned>(L.t) * o.n_pairs + p), edge_tag(c, lay, edge), nv);
-      reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.x) + static_cast<size_t>(L.t) * a.d_model)[p] = nv;
+      store_granule(e.gran, e.tag, nv);
+      *e.res = nv;
+      *e.xtap = nv;
     }
   } else if (o.kind == POP_GATEUP) {
     unsigned u = 0;
-    if (valid) u = float_to_bf16_bits(y0 / (1.0f + __expf(-y0)) * y1);
+    if (e.valid) u = float_to_bf16_bits(y0 / (1.0f + __expf(-y0)) * y1);
     const unsigned partner = __shfl_xor(u, 1, 64);
-    if (valid && (L.jp & 1) == 0) {
+    if (e.valid && (L.jp & 1) == 0) {
       const unsigned v = u | (partner << 16);
-      store_granule(granule_ptr(a, o.layer, PE_ACT, static_cast<unsigned>(L.t) * (o.n_pairs >> 1) + (p >> 1)), edge_tag(c, o.layer, PE_ACT), v);
-      reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.act) + static_cast<size_t>(L.t) * a.d_ff)[p >> 1] = v;
+      store_granule(e.gran, e.tag, v);
+      *e.acttap = v;
     }
   } else {   // POP_HEAD: logits are the bf16-rounded products (epilogue<EPI_ARGMAX>)
-    if (valid) {
-      const int r0 = 2 * p, r1 = 2 * p + 1;
+    if (e.valid) {
+      const int r0 = 2 * e.p, r1 = 2 * e.p + 1;
       const uint16_t u0 = float_to_bf16_bits(y0), u1 = float_to_bf16_bits(y1);
       const float f0 = bf16_bits_to_float(u0), f1 = bf16_bits_to_float(u1);
       if (argmax_better(f0, r0, st.best_v, st.best_i)) { st.best_v = f0; st.best_i = r0; }
@@ -345,103 +449,179 @@ __device__ __forceinline__ void leader_epilogue(const PCtx& c, const OpView& o, 
   }
 }
 
-// The MFMA part of one op, for consumer cw (0 = leader, 1 = gatherer, 2 = plain). Tiles of <= 8 pairs; the 8-step chunks of a
-// tile go round-robin over the three consumers. A wave alone on its SIMD hides nothing: every wait, branch and address
-// computation is paid in full (4-step groups with a wait each ran at 650-1000 cycles per group, 27 GB/s per CU, measured).
-// So a chunk is 16 LDS reads issued back to back, then 8 MFMAs on two alternating accumulators, and one flag update.
+// The MFMA part of one op, for consumer cw (0 = leader, 1 = gatherer, 2 = plain). Tiles of <= 8 pairs. A wave alone on its
+// SIMD hides nothing: every wait, branch and address computation is paid in full (4-step groups with a wait each ran at
+// 650-1000 cycles per group, measured). So the unit of work is a CHUNK: 16 LDS reads issued back to back, then 8 MFMAs on
+// two alternating accumulators, and one flag update; the chunks of a tile go round-robin over the participating waves.
+//   * Tiles of 4 pairs (the d_model-wide matrices at 256 workgroups: out- and down-projection) fill only 8 of the 16 MFMA
+//     rows. They are multiplied TWO steps per MFMA: a lane's 16 bytes are chunk `lane` of the 1-KiB double step, which puts
+//     (step 2j + g/2, k group 2 (g % 2)) of row n under MFMA row n < 8 and k group 2 (g % 2) + 1 of row n - 8 under MFMA
+//     row n >= 8; token t supplies its even-group activations as B column 2 t and the odd groups as column 2 t + 1, so
+//     D[r][2t] + D[r + 8][2t + 1] is row r's sum (the cross terms are never read). Half the MFMAs and LDS reads per byte.
+//   * The leader multiplies only in long single-tile ops (>= 96 MFMAs: the down-projection); in short ops it is worth more
+//     with its epilogue operands ready when the partials arrive, in ops of several tiles (gate/up, lm_head) its epilogue of
+//     tile i runs while the other two are in tile i + 1.
 // Returns false when the wave gave up.
-constexpr int kChunk = 8;
+constexpr int kChunk = SD_P_CHUNK;
 
-template <bool LEAD, bool DIAG = false>
+// one chunk: UB / XS = byte strides of the weight fragments / activation fragments (0: run-time values ub / xs)
+struct ChunkDiag { unsigned long long reads, mfma, wait, spins, chunks, other; };
+
+// WRAP: the chunk may run past the end of the ring: every lane wraps its own address (min(a, a - ring) on unsigned values)
+template <unsigned UB, unsigned XS, bool WRAP, bool DIAG = false>
+__device__ __forceinline__ void chunk_mfma(const unsigned char* ringp, unsigned woff, unsigned ring, const unsigned char* xb, unsigned ub, unsigned xs,
+                                           f32x4_t& acc0, f32x4_t& acc1, ChunkDiag* dg = nullptr) {
+  u32x4 wf[kChunk], xf[kChunk];
+  unsigned long long t0 = 0;
+  if constexpr (DIAG) t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int j = 0; j < kChunk; ++j) {
+    unsigned ra = woff + static_cast<unsigned>(j) * (UB ? UB : ub);
+    if constexpr (WRAP) ra = min(ra, ra - ring);
+    wf[j] = *reinterpret_cast<const u32x4*>(ringp + ra);
+    xf[j] = *reinterpret_cast<const u32x4*>(xb + static_cast<unsigned>(j) * (XS ? XS : xs));
+  }
+  // all 16 reads are issued before the first MFMA (hipcc otherwise keeps two pairs in flight and exposes the LDS latency
+  // eight times per chunk); the waits become counted lgkmcnt(N)
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t1 = 0;
+  if constexpr (DIAG) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < kChunk; j += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[j]), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j + 1]), __builtin_bit_cast(bf16x8_t, xf[j + 1]), acc1, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DIAG) {
+    asm volatile("s_nop 0" :: "v"(acc0[0]), "v"(acc1[0]));   // the sums have to be there
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    dg->reads += t1 - t0;
+    dg->mfma += t2 - t1;
+    dg->chunks += 1;
+  }
+}
+
+template <bool DIAG = false>
 __device__ __forceinline__ bool consume_op(const PCtx& c, int cw, const OpView& o, ConsState& st, const LeadLane& L, int ts_mfma) {
-  // DIAG (timeline runs only, third consumer): shader cycles spent waiting for weights / in the chunk bodies, chunks by path
-  unsigned long long d_wait = 0, d_body = 0, d_fast = 0, d_slow = 0, d_t = 0;
+  // ONE copy of this routine for the three consumers (the leader's parts under a wave-uniform branch): the launch's code must
+  // stay inside the 64 KiB instruction cache two CUs share — with a copy per role (and per call site of the gathers) the
+  // kernel was ~150 KiB and every phase of every wave started on instructions fetched from memory
+  const bool LEAD = cw == 0;
   const PersistArgs& a = *c.a;
+  ChunkDiag dg{};
+  unsigned long long d_t = 0, d_loop0 = 0;
+  if constexpr (DIAG) d_loop0 = __builtin_amdgcn_s_memtime();
   const int lane = c.lane, g = lane >> 4, n = lane & 15;
   const unsigned ring = a.ring_bytes;
   const unsigned char* ringp = c.smem + a.lds_ring;
-  const unsigned char* xrow = c.smem + a.lds_u + static_cast<unsigned>(n < c.T ? n : 0) * a.u_stride + g * 16;
+  const unsigned char* ubase = c.smem + a.lds_u;
+  const unsigned char* xrow_std = ubase + static_cast<unsigned>(n < c.T ? n : 0) * a.u_stride + g * 16;
+  const unsigned char* xrow_dbl = ubase + static_cast<unsigned>((n >> 1) < c.T ? (n >> 1) : 0) * a.u_stride + g * 32 + (n & 1) * 16;
   float* part_all = reinterpret_cast<float*>(c.smem + a.lds_part);
   const unsigned op_abs0 = st.piece0 * kPiece;
-  const int n_chunk = (o.steps + kChunk - 1) / kChunk;
+  const bool multi = o.n_tiles > 1;
+  const bool dbl0 = !multi && o.my_pairs == 4 && (o.steps & 1) == 0;
+  const int units0 = dbl0 ? o.steps >> 1 : o.steps;
+  const bool lead_in = !multi && units0 >= 96;
+  const int share = lead_in ? 3 : 2;
+  // (when it does multiply, the leader takes the short share: chunk 2, 5, ... of a tile)
+  const int first_chunk = lead_in ? (cw + 2) % 3 : cw - 1;   // -1: this wave (the leader) does not multiply in this op
+  if (LEAD && !lead_in) lds_st(&c.ctl->consumed[0], st.piece0 + o.pieces);   // never reads this op's weights
   for (int tile = 0; tile < o.n_tiles; ++tile) {
     const int np = min(o.tile_pairs, o.my_pairs - tile * o.tile_pairs);
+    const bool dbl = np == 4 && (o.steps & 1) == 0;
     const unsigned sb = static_cast<unsigned>(np) * 128u;   // bytes of one 32-k step of the tile
+    const unsigned ub = dbl ? 1024u : sb;                   // bytes of one MFMA's worth (a "unit")
+    const int units = dbl ? o.steps >> 1 : o.steps;
+    const int n_chunk = (units + kChunk - 1) / kChunk;
     const unsigned tile_off = static_cast<unsigned>(tile * o.tile_pairs) * o.pair_bytes;
     int jp = n & 7, second = n >> 3;
     if (jp >= np) { jp = 0; second = 0; }   // lanes without a pair alias the first row (their outputs are never read)
-    const unsigned lane_off = static_cast<unsigned>(g * 2 * np + second * np + jp) * 16u;   // + 16 <= sb
+    const unsigned lane_off = dbl ? static_cast<unsigned>(lane) * 16u : static_cast<unsigned>(g * 2 * np + second * np + jp) * 16u;   // + 16 <= ub
+    const unsigned char* xrow = dbl ? xrow_dbl : xrow_std;
+    const unsigned xstep = dbl ? 128u : 64u;
+    EpiPrep prep{};
+    if (LEAD) prep = epilogue_prep(c, o, tile, np, L);
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = cw; ch < n_chunk; ch += 3) {
-      const unsigned off = tile_off + static_cast<unsigned>(ch * kChunk) * sb;
-      const int ns = min(kChunk, o.steps - ch * kChunk);
-      const unsigned need = st.piece0 + ((off + static_cast<unsigned>(ns) * sb + kPiece - 1) / kPiece);
+    for (int ch = first_chunk; ch >= 0 && ch < n_chunk; ch += share) {
+      const unsigned off = tile_off + static_cast<unsigned>(ch * kChunk) * ub;
+      const int ns = min(kChunk, units - ch * kChunk);
+      const unsigned need = st.piece0 + ((off + static_cast<unsigned>(ns) * ub + kPiece - 1) / kPiece);
       if constexpr (DIAG) d_t = __builtin_amdgcn_s_memtime();
       if (st.landed < need) {
         for (unsigned spins = 1;; ++spins) {
           st.landed = lds_ld(&c.ctl->landed);
+          if constexpr (DIAG) dg.spins += 1;
           if (st.landed >= need) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_LANDED); return false; }
+          if ((spins & 1023u) == 0u && expired(c)) { give_up(c, ST_LANDED); return false; }
         }
       }
-      if constexpr (DIAG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); d_wait += t - d_t; d_t = t; }
+      if constexpr (DIAG) dg.wait += __builtin_amdgcn_s_memtime() - d_t;
       const unsigned abs0 = op_abs0 + off;
       while (abs0 - st.rbase >= ring) st.rbase += ring;
       const unsigned pos = abs0 - st.rbase;
-      const unsigned char* xb = xrow + ch * (kChunk * 64);
-      if (ns == kChunk && pos + kChunk * sb <= ring) {
-        const unsigned char* wb = ringp + pos + lane_off;
-        u32x4 wf[kChunk], xf[kChunk];
-#pragma unroll
-        for (int j = 0; j < kChunk; ++j) {
-          wf[j] = *reinterpret_cast<const u32x4*>(wb + static_cast<unsigned>(j) * sb);
-          xf[j] = *reinterpret_cast<const u32x4*>(xb + j * 64);
-        }
-        // all 16 reads are issued before the first MFMA (hipcc otherwise keeps two pairs in flight and exposes the LDS latency
-        // eight times per chunk: 1900 cycles per chunk, measured); the waits become counted lgkmcnt(N)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < kChunk; j += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[j]), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j + 1]), __builtin_bit_cast(bf16x8_t, xf[j + 1]), acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DIAG) ++d_fast;
-      } else {   // the chunk wraps around the ring, or is the short last one of the tile
+      const unsigned char* xb = xrow + static_cast<unsigned>(ch * kChunk) * xstep;
+      if (ns == kChunk) {
+        const unsigned woff = pos + lane_off;
+        const bool wraps = pos + kChunk * ub > ring;
+        // 1-KiB units (8-pair tiles and double-stepped 4-pair tiles: gate/up, lm_head, out- and down-projection = 90 % of the
+        // bytes): compile-time strides, so the reads carry immediate offsets and cost no address arithmetic. A chunk that runs
+        // past the end of the ring (one in eight at 16 KiB) wraps per lane — still all reads first (as a serial loop of
+        // read, wait, MFMA such a chunk cost 3200 cycles against 700, and doubled the time of every op; measured)
+        if (ub == 1024u && !dbl && !wraps) chunk_mfma<1024, 64, false, DIAG>(ringp, woff, ring, xb, 0u, 0u, acc0, acc1, &dg);
+        else if (ub == 1024u && dbl && !wraps) chunk_mfma<1024, 128, false, DIAG>(ringp, woff, ring, xb, 0u, 0u, acc0, acc1, &dg);
+        else if (ub == 768u && !wraps) chunk_mfma<768, 64, false, DIAG>(ringp, woff, ring, xb, 0u, 0u, acc0, acc1, &dg);   // 6-pair tiles: Llama-3.2-1B QKV
+        else chunk_mfma<0, 0, true, DIAG>(ringp, woff, ring, xb, ub, xstep, acc0, acc1, &dg);
+      } else {   // the short last chunk of a tile whose steps are not a multiple of the chunk
         for (int j = 0; j < ns; ++j) {
-          unsigned ra = pos + static_cast<unsigned>(j) * sb + lane_off;
+          unsigned ra = pos + static_cast<unsigned>(j) * ub + lane_off;
           ra = (ra >= ring) ? ra - ring : ra;
           const u32x4 wf = *reinterpret_cast<const u32x4*>(ringp + ra);
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + j * 64);
+          const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + static_cast<unsigned>(j) * xstep);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf), acc0, 0, 0, 0);
         }
-        if constexpr (DIAG) ++d_slow;
       }
-      if constexpr (DIAG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); d_body += t - d_t; }
       // first piece this wave still needs: its next chunk of this tile, or the end of the tile (the next tile / op starts there)
-      const unsigned nxt_off = (ch + 3 < n_chunk) ? off + 3u * kChunk * sb : tile_off + static_cast<unsigned>(o.steps) * sb;
+      const unsigned nxt_off = (ch + share < n_chunk) ? off + static_cast<unsigned>(share * kChunk) * ub : tile_off + static_cast<unsigned>(o.steps) * sb;
       lds_st(&c.ctl->consumed[cw], st.piece0 + nxt_off / kPiece);
     }
     if (tile == o.n_tiles - 1 && ts_mfma >= 0) stamp(c, ts_mfma);   // diagnostic: this wave's MFMA part of the op is done
     if constexpr (DIAG) {
       if (tile == o.n_tiles - 1 && ts_mfma >= 0 && c.lane == 0) {
         unsigned long long* d = c.a->debug_ts + static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + ts_mfma + 3;   // slots 8..11 of the op
-        d[0] = d_wait; d[1] = d_body; d[2] = d_fast; d[3] = d_slow;
+        d[0] = dg.wait; d[1] = dg.reads; d[2] = dg.mfma; d[3] = (dg.chunks << 32) | ((__builtin_amdgcn_s_memtime() - d_loop0) & 0xffffffffull);
       }
     }
     // ---- hand the partial to the leader (double-buffered by tile parity)
     if (st.tile_no >= 2 && !wait_word<1>(c, &c.ctl->lead_done, st.tile_no - 1, ST_PART)) return false;
     float* part = part_all + (st.tile_no & 1u) * (3 * 16 * kPartT);
-    if (n < c.T) {
+    if (first_chunk >= 0) {
+      if (dbl) {   // MFMA rows < 8 count in the even token columns, rows >= 8 in the odd ones
+        if (((g < 2) == ((n & 1) == 0)) && (n >> 1) < c.T) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) part[(cw * 16 + 4 * g + q) * kPartT + n] = acc0[q] + acc1[q];
+          for (int q = 0; q < 4; ++q) part[(cw * 16 + 4 * g + q) * kPartT + (n >> 1)] = acc0[q] + acc1[q];
+        }
+      } else if (n < c.T) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[(cw * 16 + 4 * g + q) * kPartT + n] = acc0[q] + acc1[q];
+      }
     }
     ++st.tile_no;
     lds_st(&c.ctl->done[cw], st.tile_no);
-    if constexpr (LEAD) {
+    if (LEAD) {
       if (!wait_word<1>(c, &c.ctl->done[1], st.tile_no, ST_PART) || !wait_word<1>(c, &c.ctl->done[2], st.tile_no, ST_PART)) return false;
-      leader_epilogue(c, o, tile, np, part, L, st);
+      if (tile == o.n_tiles - 1 && ts_mfma >= 0) stamp(c, ts_mfma + 3);   // diagnostic (slot 9): the last tile's partials are in
+      if (lead_in) {
+        if (dbl) epilogue_finish<0, true>(c, o, prep, part, L, st);
+        else epilogue_finish<0, false>(c, o, prep, part, L, st);
+      } else {
+        if (dbl) epilogue_finish<1, true>(c, o, prep, part, L, st);
+        else epilogue_finish<1, false>(c, o, prep, part, L, st);
+      }
       lds_st(&c.ctl->lead_done, st.tile_no);
     }
   }
@@ -453,14 +633,18 @@ __device__ __forceinline__ bool consume_op(const PCtx& c, int cw, const OpView& 
 // ---- gatherer (consumer 1): sweep granules ----------------------------------------------------------------------------
 // The staged rows of the previous op may still be read by the other two consumers' MFMAs: they are free once both have
 // handed in the partial of the op's last tile. The sweep's loads are issued BEFORE this wait.
-__device__ __forceinline__ bool wait_rows_free(const PCtx& c, const ConsState& st) {
-  return wait_word<1>(c, &c.ctl->done[0], st.tile_no, ST_PART) && wait_word<1>(c, &c.ctl->done[2], st.tile_no, ST_PART);
+__device__ __forceinline__ bool wait_rows_free(const PCtx& c, const ConsState& st, int me = 1) {
+  const int o1 = (me + 1) % 3, o2 = (me + 2) % 3;
+  return wait_word<1>(c, &c.ctl->done[o1], st.tile_no, ST_PART) && wait_word<1>(c, &c.ctl->done[o2], st.tile_no, ST_PART);
 }
 
 // NC chunks of 1024 granules (index k * 1024 + j * 64 + lane), all 16 * NC loads of a lane in flight: ONE round trip per
 // pass; re-read until every tag matches. The loads are UNCONDITIONAL (lanes past `count` re-read the last granule): a load
 // under `if (idx < count)` is compiled into its own exec-masked block with a vmcnt(0) behind it, i.e. 16 * NC serial
 // round trips of 0.4 us (measured: 7 us per 8 KiB vector, 26 us per 32 KiB).
+// TWO passes are kept in flight, half a round trip apart: a pass that was issued just before the last producer's granule
+// became visible comes back incomplete, and with one pass at a time the next one only starts then (a full round trip, ~1.2 us,
+// lost on most edges; measured 3.7 us from the last publish to the staged vector for an 8 KiB edge).
 template <int NC>
 __device__ __forceinline__ bool sweep(const PCtx& c, const unsigned long long* base, unsigned first, int count, unsigned tag, unsigned (&v)[NC][16]) {
   const PersistArgs& a = *c.a;
@@ -472,12 +656,14 @@ __device__ __forceinline__ bool sweep(const PCtx& c, const unsigned long long* b
       const int idx = k * 1024 + j * 64 + c.lane;
       p[k][j] = base + granule_slot(a, first + static_cast<unsigned>(idx < count ? idx : count - 1));
     }
-  for (unsigned spins = 1;; ++spins) {
-    unsigned long long x[NC][16];
+  unsigned long long xa[NC][16], xb[NC][16];
+  auto issue = [&](unsigned long long (&x)[NC][16]) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[k][j] = __hip_atomic_load(p[k][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto complete = [&](const unsigned long long (&x)[NC][16]) {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
@@ -486,16 +672,34 @@ __device__ __forceinline__ bool sweep(const PCtx& c, const unsigned long long* b
         v[k][j] = static_cast<unsigned>(x[k][j]);
         ok &= static_cast<unsigned>(x[k][j] >> 32) == tag;
       }
-    if (__all(ok)) return true;
-    __builtin_amdgcn_s_sleep(2);
+    return __all(ok) != 0;
+  };
+#if SD_P_PIPEPOLL
+  issue(xa);
+  __builtin_amdgcn_s_sleep(8);
+  for (unsigned spins = 1;; ++spins) {
+    issue(xb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (complete(xa)) return true;    // (waits for pass A only: pass B's loads are younger)
+    issue(xa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (complete(xb)) return true;
+    if ((spins & 127u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
+  }
+#else
+  for (unsigned spins = 1;; ++spins) {
+    issue(xa);
+    if (complete(xa)) return true;
+    __builtin_amdgcn_s_sleep(SD_P_BACKOFF);
     if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
   }
+#endif
 }
 
 // input rows of a norm-fused op (QKV, GATEUP, HEAD): gather the d_model-wide rows (granules of edge `edge`, or the
 // embedding rows for layer 0), RMSNorm them (HF LlamaRMSNorm: weight * (x * rsqrt(mean(x^2) + eps)).to(bf16)), stage as bf16
 template <int HC>
-__device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o, int edge, bool from_embedding, const ConsState& st) {
+__device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts) {
   const PersistArgs& a = *c.a;
   const int npt = a.d_model >> 1;   // dwords (pairs) per row
   const unsigned* nw = static_cast<const unsigned*>(o.norm_w);
@@ -544,7 +748,7 @@ __device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o,
       }
     const float sq = wave_reduce_sum(s2.x + s2.y);
     const float rs = rsqrtf(sq / static_cast<float>(a.d_model) + a.norm_eps);
-    if (t == 0 && !wait_rows_free(c, st)) return false;
+    if (t == 0) { if (ts >= 0) stamp(c, ts + 8); if (!wait_rows_free(c, st)) return false; }
     unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u + static_cast<unsigned>(t) * a.u_stride);
 #pragma unroll
     for (int hc = 0; hc < HC; ++hc)
@@ -560,10 +764,10 @@ __device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o,
 // input rows taken as they are (attention rows for the out-projection, activations for the down-projection)
 template <int NC>
 __device__ __forceinline__ bool gather_plain_chunks(const PCtx& c, const unsigned long long* g, unsigned first, int count, unsigned tag, unsigned* dst,
-                                                    int dst0, bool& first_write, const ConsState& st) {
+                                                    int dst0, bool& first_write, const ConsState& st, int me) {
   unsigned v[NC][16];
   if (!sweep<NC>(c, g, first, count, tag, v)) return false;
-  if (first_write && !wait_rows_free(c, st)) return false;
+  if (first_write && !wait_rows_free(c, st, me)) return false;
   first_write = false;
 #pragma unroll
   for (int k = 0; k < NC; ++k)
@@ -575,41 +779,45 @@ __device__ __forceinline__ bool gather_plain_chunks(const PCtx& c, const unsigne
   return true;
 }
 
-__device__ __forceinline__ bool gather_plain_rows(const PCtx& c, int layer, int edge, int npt, const ConsState& st) {
+// granules [lo, hi) of every token row (npt per row); wave `me` of the three consumers does the sweeping
+__device__ __forceinline__ bool gather_plain_rows(const PCtx& c, int layer, int edge, int npt, int lo, int hi, const ConsState& st, int me) {
   const PersistArgs& a = *c.a;
   const unsigned tag = edge_tag(c, layer, edge);
   const unsigned long long* g = edge_base(a, layer, edge);
   bool first_write = true;
   for (int t = 0; t < c.T; ++t) {
     unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u + static_cast<unsigned>(t) * a.u_stride);
-    for (int c0 = 0; c0 < npt;) {
-      const int left = npt - c0;
+    for (int c0 = lo; c0 < hi;) {
+      const int left = hi - c0;
       const unsigned first = static_cast<unsigned>(t * npt + c0);
       bool ok;
-      if (left > 2048) { ok = gather_plain_chunks<4>(c, g, first, left < 4096 ? left : 4096, tag, dst, c0, first_write, st); c0 += 4096; }
-      else if (left > 1024) { ok = gather_plain_chunks<2>(c, g, first, left, tag, dst, c0, first_write, st); c0 += 2048; }
-      else { ok = gather_plain_chunks<1>(c, g, first, left, tag, dst, c0, first_write, st); c0 += 1024; }
+      if (left > 1024) { ok = gather_plain_chunks<2>(c, g, first, left < 2048 ? left : 2048, tag, dst, c0, first_write, st, me); c0 += 2048; }
+      else { ok = gather_plain_chunks<1>(c, g, first, left, tag, dst, c0, first_write, st, me); c0 += 1024; }
       if (!ok) return false;
     }
   }
   return true;
 }
+// rows wider than this many granules are swept by two waves (the gatherer and the third consumer, half each): a 64-load
+// pass of one wave took 3 us, and a pass that starts before the last producer has published is a pass lost
+constexpr int kSplitSweep = SD_P_SPLIT;
 
 // ---- attention of one (row b, q head h) unit, by the three consumer waves of its CU ---------------------------------
-// LDS scratch at lds_attn: q_s [M][D] bf16 | k_s [M][D] | v_s [M][D] | o_s [3][M][D] f32 | m_s [3][8] | l_s [3][8]
+// LDS scratch at lds_attn: q_s [M][D] bf16 | k_s [M][D] | vT_s [D][8] (V of the new positions, transposed, zero beyond M) |
+//                          o_s [3][M][D] f32 | m_s [3][8] | l_s [3][8]
 // The gatherer sweeps q / new k / new v of the unit; every wave has the K / V operands of its first cached block in flight
 // before it waits for them; the cached 32-key blocks go round-robin over the waves, the block of the M new positions (from
 // LDS) to the wave whose turn it is; the leader merges the three partials and publishes the rows.
 template <int D>
-__device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer, int b, int h, ConsState& st) {
+__device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer, int b, int h, ConsState& st, int ts) {
   const PersistArgs& a = *c.a;
   constexpr int NKS = D / 32, NDT = D / 16;
   const int lane = c.lane, g = lane >> 4, n = lane & 15;
   const int M = a.M, Hq = a.n_q_heads, Hkv = a.n_kv_heads, G = Hq / Hkv, kvh = h / G, half = D / 2;
   uint16_t* q_s = reinterpret_cast<uint16_t*>(c.smem + a.lds_attn);
   uint16_t* k_s = q_s + M * D;
-  uint16_t* v_s = k_s + M * D;
-  float* o_s = reinterpret_cast<float*>(v_s + M * D);
+  uint16_t* vT_s = k_s + M * D;
+  float* o_s = reinterpret_cast<float*>(vT_s + 8 * D);
   float* m_s = o_s + 3 * M * D;
   float* l_s = m_s + 3 * 8;
   const int pos0 = max(0, min(a.pos_base[b] + a.pos_off, a.l_max));   // cached keys [0, pos0); new keys pos0 + m
@@ -641,6 +849,7 @@ __device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer,
   if (cw != 0 && st.att_no > 0 && !wait_word<1>(c, &c.ctl->a_merged, st.att_no, ST_ATTN)) return false;
 
   if (cw == 1) {
+    if (SD_P_THINATT) lds_st(&c.ctl->gathering, 1u);
     // sweep q_h, k_kvh, v_kvh of the M new positions: granule (t, pair p) holds rows (i, i + half) of head p / half.
     // 3 * half granules per position = NL loads per lane, unconditional (clamped) and all in flight (see sweep)
     constexpr int NL = (3 * (D / 2) + 63) / 64;
@@ -663,29 +872,47 @@ __device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer,
         p[l] = gq + granule_slot(a, g0 + head * half + ii[l]);
       }
       unsigned val[NL];
-      for (unsigned spins = 1;; ++spins) {
-        unsigned long long x[NL];
+      unsigned long long xa[NL], xb[NL];
+      auto issue = [&](unsigned long long (&x)[NL]) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) x[l] = __hip_atomic_load(p[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto complete = [&](const unsigned long long (&x)[NL]) {
         bool ok = true;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           val[l] = static_cast<unsigned>(x[l]);
           ok &= static_cast<unsigned>(x[l] >> 32) == tag;
         }
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
+        return __all(ok) != 0;
+      };
+      issue(xa);   // two passes in flight (see sweep)
+      __builtin_amdgcn_s_sleep(8);
+      for (unsigned spins = 1;; ++spins) {
+        issue(xb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (complete(xa)) break;
+        issue(xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (complete(xb)) break;
+        if ((spins & 127u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l)
         if (act[l]) {
-          uint16_t* dst = (sel[l] == 0 ? q_s : (sel[l] == 1 ? k_s : v_s)) + m * D + ii[l];
-          dst[0] = static_cast<uint16_t>(val[l]);
-          dst[half] = static_cast<uint16_t>(val[l] >> 16);
+          if (sel[l] == 2) {   // V: channel-major, position m in slot m
+            vT_s[ii[l] * 8 + m] = static_cast<uint16_t>(val[l]);
+            vT_s[(ii[l] + half) * 8 + m] = static_cast<uint16_t>(val[l] >> 16);
+          } else {
+            uint16_t* dst = (sel[l] == 0 ? q_s : k_s) + m * D + ii[l];
+            dst[0] = static_cast<uint16_t>(val[l]);
+            dst[half] = static_cast<uint16_t>(val[l] >> 16);
+          }
         }
     }
+    if (SD_P_THINATT) lds_st(&c.ctl->gathering, 0u);
     lds_st(&c.ctl->a_seq, unit_no);
+    stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
   } else {
     if (!wait_word<1>(c, &c.ctl->a_seq, unit_no, ST_ATTN)) return false;
   }
@@ -769,14 +996,9 @@ __device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer,
       for (int s = 0; s < NKS; ++s) kf[u][s] = (j < M) ? *reinterpret_cast<const u32x4*>(k_s + j * D + s * 32 + g * 8) : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
-    for (int i = 0; i < NDT; ++i) {
-      unsigned w[4] = {0u, 0u, 0u, 0u};
-      if (g == 0) {   // keys 8 g + jj < M <= 8 only exist for g = 0
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-          if (jj < M) w[jj >> 1] |= static_cast<unsigned>(v_s[jj * D + 16 * i + n]) << (16 * (jj & 1));
-      }
-      vf[i] = u32x4{w[0], w[1], w[2], w[3]};
+    for (int i = 0; i < NDT; ++i) {   // keys 8 g + jj < M <= 8 only exist for g = 0; slots >= M of a channel are zero
+      const u32x4 w = *reinterpret_cast<const u32x4*>(vT_s + (16 * i + n) * 8);
+      vf[i] = (g == 0) ? w : u32x4{0u, 0u, 0u, 0u};
     }
     block(kf, vf, 0, true);
   }
@@ -794,6 +1016,7 @@ __device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer,
   lds_st(&c.ctl->a_done[cw], unit_no);
   if (cw == 0) {
     if (!wait_word<1>(c, &c.ctl->a_done[1], unit_no, ST_ATTN) || !wait_word<1>(c, &c.ctl->a_done[2], unit_no, ST_ATTN)) return false;
+    stamp(c, ts + 11);   // diagnostic: the three partials are in
     const unsigned tag = edge_tag(c, layer, PE_ATTN);
     for (int it = lane; it < M * half; it += 64) {
       const int r = it / half, dj = it - r * half;
@@ -876,34 +1099,46 @@ __device__ __forceinline__ void consumer_role(const PCtx& c, int cw) {
 
   for (int i = 0; i < a.n_ops; ++i) {
     const OpView o = load_op(c, i);
-    if (cw == 1) {
-      stamp(c, 12 * i + 0);
-      bool ok;
-      if (o.kind == POP_QKV) ok = gather_norm_rows<HC>(c, o, PE_X, o.layer == 0, st);
-      else if (o.kind == POP_OUT) ok = gather_plain_rows(c, o.layer, PE_ATTN, (a.n_q_heads * a.head_dim) >> 1, st);
-      else if (o.kind == POP_GATEUP) ok = gather_norm_rows<HC>(c, o, PE_X2, false, st);
-      else if (o.kind == POP_DOWN) ok = gather_plain_rows(c, o.layer, PE_ACT, a.d_ff >> 1, st);
-      else ok = gather_norm_rows<HC>(c, o, PE_X, a.n_layers == 0, st);   // head: rows left by the last down-projection (layer index n_layers)
-      if (!ok) return;
-      lds_st(&c.ctl->u_seq, static_cast<unsigned>(i + 1));
-      stamp(c, 12 * i + 1);
-      if (!consume_op<false>(c, 1, o, st, L, -1)) return;
-    } else {
-      if (!wait_word<1>(c, &c.ctl->u_seq, static_cast<unsigned>(i + 1), ST_USEQ)) return;
-      if (cw == 0) {
-        if (!consume_op<true>(c, 0, o, st, L, 12 * i + 6)) return;
-        stamp(c, 12 * i + 2);
-      } else {
-        stamp(c, 12 * i + 4);
-        if (a.debug_ts) {
-          if (!consume_op<false, true>(c, 2, o, st, L, 12 * i + 5)) return;
-        } else {
-          if (!consume_op<false>(c, 2, o, st, L, 12 * i + 5)) return;
-        }
+    // ---- the op's input rows: the gatherer stages them (the third consumer sweeps the second half of wide plain rows).
+    //      One call site per routine: see consume_op on code size.
+    const bool normed = o.kind == POP_QKV || o.kind == POP_GATEUP || o.kind == POP_HEAD;
+    if (cw == 1) stamp(c, 12 * i + 0);
+    if (SD_P_THIN && cw == 1) lds_st(&c.ctl->gathering, 1u);
+    bool ok = true;
+#if SD_P_GWAIT
+    // the workgroups run in near lockstep: before this CU's own leader has published the previous op, no sweep can complete
+    if (cw != 0 && !wait_word<1>(c, &c.ctl->lead_done, st.tile_no, ST_PART)) return;
+#endif
+    if (normed) {
+      if (cw == 1) {
+        const int edge = (o.kind == POP_GATEUP) ? PE_X2 : PE_X;   // the head reads the rows the last down-projection left (layer index n_layers)
+        const bool emb = (o.kind == POP_QKV && o.layer == 0) || (o.kind == POP_HEAD && a.n_layers == 0);
+        ok = gather_norm_rows<HC>(c, o, edge, emb, st, 12 * i);
+      }
+    } else if (cw != 0) {
+      const int edge = (o.kind == POP_OUT) ? PE_ATTN : PE_ACT;
+      const int npt = (o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1;
+      const int mid = (npt > kSplitSweep) ? ((npt >> 1) + 1023) & ~1023 : npt;
+      const int lo = (cw == 1) ? 0 : mid, hi = (cw == 1) ? mid : npt;
+      if (lo < hi) ok = gather_plain_rows(c, o.layer, edge, npt, lo, hi, st, cw);
+      if (ok && mid < npt) {
+        if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
+        else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ);   // the third consumer's half
       }
     }
+    if (!ok) return;
+    if (cw == 1) {
+      if (SD_P_THIN) lds_st(&c.ctl->gathering, 0u);
+      lds_st(&c.ctl->u_seq, static_cast<unsigned>(i + 1));
+      stamp(c, 12 * i + 1);
+    } else {
+      if (!wait_word<1>(c, &c.ctl->u_seq, static_cast<unsigned>(i + 1), ST_USEQ)) return;
+      if (cw == 2) stamp(c, 12 * i + 4);
+    }
+    if (!consume_op(c, cw, o, st, L, cw == 0 ? 12 * i + 6 : (cw == 2 ? 12 * i + 5 : -1))) return;
+    if (cw == 0) stamp(c, 12 * i + 2);
     if (o.kind == POP_QKV && unit >= 0) {
-      if (!attention_unit<D>(c, cw, o.layer, unit / a.n_q_heads, unit % a.n_q_heads, st)) return;
+      if (!attention_unit<D>(c, cw, o.layer, unit / a.n_q_heads, unit % a.n_q_heads, st, 12 * i)) return;
       if (cw == 0) stamp(c, 12 * i + 3);
     }
   }
@@ -931,6 +1166,8 @@ __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < 64) reinterpret_cast<unsigned*>(smem)[tid] = 0u;
+  // V^T scratch of the new positions (attention_unit): key slots >= M are never written and must read as zero
+  for (int i = tid; i < 4 * D; i += 256) reinterpret_cast<unsigned*>(smem + a.lds_attn + 2 * a.M * D * 2)[i] = 0u;
   const unsigned launch = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   PCtx c;
@@ -980,7 +1217,7 @@ static LdsPlan plan_lds(int d_model, int HqD, int d_ff, int head_dim, int T, int
   p.part = off;
   off += 2 * 3 * 16 * kPartT * 4;
   p.attn = off;
-  off += align16(static_cast<unsigned>(3 * M * head_dim * 2 + 3 * M * head_dim * 4 + 2 * 3 * 8 * 4));
+  off += align16(static_cast<unsigned>((2 * M + 8) * head_dim * 2 + 3 * M * head_dim * 4 + 2 * 3 * 8 * 4));
   p.u = off;
   p.u_stride = static_cast<unsigned>(kmax + kXPad) * 2;
   off += align16(static_cast<unsigned>(T) * p.u_stride);

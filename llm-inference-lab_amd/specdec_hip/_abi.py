@@ -84,7 +84,7 @@ SIGNATURES = {
     "sd_model_persist_tokens": (_c_int, [_c_void_p]),
     "sd_model_engine_status": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_uint32), _c_void_p]),
     "sd_model_debug_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
-    "sd_model_probe_forward": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, ctypes.POINTER(ctypes.c_float),
+    "sd_model_probe_forward": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_double), _c_void_p, _c_size]),
     "sd_specdec_create": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "sd_specdec_destroy": (_c_int, [_c_void_p]),

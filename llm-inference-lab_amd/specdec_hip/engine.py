@@ -259,7 +259,7 @@ class HipModel:
         return out
 
     def probe_forward(self, M: int = 1, iters: int = 50, skip_head: bool = False, timeline: bool = False,
-                      stream: Optional[torch.cuda.Stream] = None):
+                      stream: Optional[torch.cuda.Stream] = None, pos0: int = 0):
         """(average microseconds per forward of M tokens, bytes of weights per forward, timeline or None): sd_model_probe_forward.
         timeline: uint64 [256][12 * n_ops + 4] stamps (100 MHz) of one persistent forward — per op: gather start, input staged,
         op done, attention done, third consumer start, its MFMA end, leader MFMA end, loader done issuing; then (realtime,
@@ -268,7 +268,7 @@ class HipModel:
         n_ops = 4 * self.cfg.n_layers + (0 if skip_head else 1)
         tl = np.zeros(256 * (12 * n_ops + 4), dtype=np.uint64) if timeline else None
         with torch.cuda.device(self.device):
-            rc = self.lib.sd_model_probe_forward(self.handle, int(M), int(iters), 1 if skip_head else 0, _stream(stream, self.device),
+            rc = self.lib.sd_model_probe_forward(self.handle, int(M), int(pos0), int(iters), 1 if skip_head else 0, _stream(stream, self.device),
                                                  ctypes.byref(usec), ctypes.byref(nbytes),
                                                  tl.ctypes.data if tl is not None else None, tl.size if tl is not None else 0)
         _abi.check(rc, "sd_model_probe_forward")

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--model", default="1b")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--tokens", type=int, default=1)
-    ap.add_argument("--ctx", type=int, default=100)
+    ap.add_argument("--ctx", type=int, default=128)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--max-t", type=int, default=2)
     ap.add_argument("--no-timeline", action="store_true")
@@ -46,9 +46,8 @@ def main():
         if a.ctx:
             toks = torch.randint(4, cfg.vocab, (1, a.ctx), dtype=torch.int32, device="cuda")
             hm.forward(toks, torch.zeros(1, dtype=torch.int32, device="cuda"), 0, skip_head=True)
-        # (the probe writes positions 0..M-1 of row 0 and attends over them only: context length 0; use --ctx for the cache
-        #  to hold data, the attention length of the probe stays M)
-        us, nbytes, tl = hm.probe_forward(M=a.tokens, iters=a.iters, timeline=(label == "persistent" and not a.no_timeline))
+        # the probe's tokens sit at positions ctx .. ctx+M-1: the attention reads the ctx cached positions
+        us, nbytes, tl = hm.probe_forward(M=a.tokens, iters=a.iters, timeline=(label == "persistent" and not a.no_timeline), pos0=a.ctx)
         st = hm.engine_status()
         res[label] = us
         print(f"{label:11s} persist_tokens={hm.persist_tokens} M={a.tokens}: {us:8.1f} us / forward, {nbytes / 1e6:8.1f} MB -> "
@@ -74,7 +73,10 @@ def main():
                 at = us_(at[at > 0]).mean() if (at > 0).any() else float("nan")
                 row = dict(gather=(e[:, 1] - e[:, 0]).mean(), w3wait=(e[:, 4] - e[:, 1]).mean(), mfma=(e[:, 5] - e[:, 4]).mean(),
                            lead_mfma=(e[:, 6] - e[:, 1]).mean(), epi=(e[:, 2] - e[:, 6]).mean(), total=(e[:, 2] - e[:, 0]).mean())
-                row.update(cyc_wait=ev[:, i, 8].mean(), cyc_body=ev[:, i, 9].mean(), n_fast=ev[:, i, 10].mean(), n_slow=ev[:, i, 11].mean())
+                def d(x, y):   # mean over CUs that have both stamps
+                    m = (ev[:, i, x] > 0) & (ev[:, i, y] > 0)
+                    return float((ev[m, i, x] - ev[m, i, y]).mean() / 100.0) if m.any() else float("nan")
+                row.update(sweep=d(8, 0), parts=d(9, 1), fin=d(2, 9), a_stage=d(10, 2), a_comp=d(11, 10), a_merge=d(3, 11))
                 tot.setdefault(kind, []).append(row)
                 if 4 <= i < 12 or i >= n_ops - 1:
                     print(f"{kind + str(i // 4):>10s} {e[:, 0].mean():9.2f} {e[:, 1].mean():9.2f} {e[:, 2].mean():9.2f} {at:8.2f} {e[:, 7].mean():9.2f} | "
@@ -82,8 +84,9 @@ def main():
             print("per op kind, mean over layers (us):")
             for k, v in tot.items():
                 print(f"  {k:7s} " + "  ".join(f"{name} {np.mean([r[name] for r in v]):6.2f}" for name in ("gather", "w3wait", "mfma", "lead_mfma", "epi", "total")) + f"   (x{len(v)})")
-                print(f"          third consumer, shader cycles per op: waiting for weights {np.mean([r['cyc_wait'] for r in v]):8.0f}, chunk bodies {np.mean([r['cyc_body'] for r in v]):8.0f}, "
-                      f"chunks fast {np.mean([r['n_fast'] for r in v]):5.1f} slow {np.mean([r['n_slow'] for r in v]):5.1f}")
+                print(f"          sweep returned {np.nanmean([r['sweep'] for r in v]):5.2f} after gather start | partials in {np.nanmean([r['parts'] for r in v]):5.2f} after staged | "
+                      f"epilogue+publish {np.nanmean([r['fin'] for r in v]):5.2f} | attention: q staged {np.nanmean([r['a_stage'] for r in v]):5.2f} after op_done, "
+                      f"blocks {np.nanmean([r['a_comp'] for r in v]):5.2f}, merge+publish {np.nanmean([r['a_merge'] for r in v]):5.2f}")
             if cfg.n_layers > 2:
                 starts = us_(ev[:, 0:4 * cfg.n_layers:4, 0]).mean(0)
                 per = np.diff(starts)
