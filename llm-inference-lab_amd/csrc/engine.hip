@@ -593,8 +593,11 @@ static int carve_workspace(sd_model* m, void* workspace) {
       add(4 * c.n_layers, c.final_norm_w, (c.vocab + 1) / 2, c.d_model, POP_HEAD, c.n_layers);
       SD_HIP_CHECK(hipMemcpy(m->p_ops, ops.data(), ops.size() * sizeof(PersistOp), hipMemcpyHostToDevice));
       int cap = persist_max_tokens(c);
-      const char* env = getenv("SPECDEC_PERSIST_MAX_T");   // tokens per pass the persistent launch takes (0 = off)
-      const int want = env ? atoi(env) : 2;
+      // tokens per pass the persistent launch takes (0 = off). Default 1: at Llama-3.2-1B dimensions a 1-token forward runs
+      // 662 us persistent against 700 us as 83 launches (128 cached positions, same box), but a 2-token pass 820-840 against 720:
+      // every hand-off carries two rows and the ring loses 16 KiB to the second staged row (profiles/round3_persist_ab.md)
+      const char* env = getenv("SPECDEC_PERSIST_MAX_T");
+      const int want = env ? atoi(env) : 1;
       m->persist_t = cap < want ? cap : want;
     }
   }

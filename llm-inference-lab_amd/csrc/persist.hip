@@ -64,6 +64,12 @@
 #ifndef SD_P_THINATT
 #define SD_P_THINATT 1     // the same while an attention CU sweeps q / k / v (-4 us per forward)
 #endif
+#ifndef SD_P_LEADQKV
+#define SD_P_LEADQKV 0     // the leader multiplies in short single-tile ops whose tiles are not 1-KiB units (QKV at 6 pairs)
+#endif
+#ifndef SD_P_SPLIT3
+#define SD_P_SPLIT3 0      // wide rows swept by all three consumers (the leader joins after its last epilogue)
+#endif
 #ifndef SD_P_INFLIGHT
 #define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
 #endif
@@ -89,6 +95,7 @@ struct PCtl {   // LDS control words (all written with relaxed workgroup-scope a
   unsigned a_done[3];    // attention partials written
   unsigned a_merged;     // attention units merged
   unsigned g2_seq;       // ops whose second half of the input rows the third consumer has staged (wide rows only)
+  unsigned g3_seq;       // the same for the leader's third (SD_P_SPLIT3)
   unsigned gathering;    // the gatherer is sweeping: the loader keeps one slot in flight (its bursts queue in front of the sweep's loads)
 };
 
@@ -112,7 +119,11 @@ __device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-struct PCtx {
+// STAMPS: the diagnostic instance of the kernel (sd_model_probe_forward's timeline). In the product instance the stamps do not
+// exist: as a run-time check of debug_ts at ~40 sites they cost 24 us per 1B forward (same-box A/B).
+template <bool STAMPS>
+struct PCtxT {
+  static constexpr bool kStamps = STAMPS;
   const PersistArgs* a;
   unsigned char* smem;
   PCtl* ctl;
@@ -126,21 +137,25 @@ struct PCtx {
 __device__ __attribute__((noinline)) bool expired_slow(const unsigned* abort_word, unsigned long long t_start) {
   return lds_ld(abort_word) != 0u || static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - t_start) > kTimeoutTicks;
 }
-__device__ __forceinline__ bool expired(const PCtx& c) { return expired_slow(&c.ctl->abort_, c.t_start); }
+template <class C>
+__device__ __forceinline__ bool expired(const C& c) { return expired_slow(&c.ctl->abort_, c.t_start); }
 __device__ __attribute__((noinline)) void give_up_slow(unsigned* abort_word, unsigned* status, unsigned code, int lane) {
   lds_st(abort_word, 1u);
   if (lane == 0) atomicOr(status, code);
 }
-__device__ __forceinline__ void give_up(const PCtx& c, unsigned code) { give_up_slow(&c.ctl->abort_, c.a->sync + 1, code, c.lane); }
-__device__ __forceinline__ void stamp(const PCtx& c, int slot) {
+template <class C>
+__device__ __forceinline__ void give_up(const C& c, unsigned code) { give_up_slow(&c.ctl->abort_, c.a->sync + 1, code, c.lane); }
+template <class C>
+__device__ __forceinline__ void stamp(const C& c, int slot) {
+  if constexpr (!C::kStamps) return;
   if (c.a->debug_ts && c.lane == 0) c.a->debug_ts[static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
 // wait until an LDS word reaches `need`
 // (no s_sleep: every wave of the workgroup owns its SIMD, so a spinning wave costs the others nothing but LDS read slots,
 //  and each hop of the intra-CU hand-overs — input staged, partial in, tile folded — sits on the layer's critical path)
-template <int NAP>
-__device__ __forceinline__ bool wait_word(const PCtx& c, const unsigned* p, unsigned need, unsigned code) {
+template <int NAP, class C>
+__device__ __forceinline__ bool wait_word(const C& c, const unsigned* p, unsigned need, unsigned code) {
   for (unsigned spins = 1; lds_ld(p) < need; ++spins) {
     if ((spins & 1023u) == 0u && expired(c)) { give_up(c, code); return false; }
   }
@@ -155,7 +170,8 @@ struct OpView {
   const char* src;
   unsigned bytes;
 };
-__device__ __forceinline__ OpView load_op(const PCtx& c, int i) {
+template <class C>
+__device__ __forceinline__ OpView load_op(const C& c, int i) {
   OpView o;
   o.kind = c.ops[i].kind;
   o.layer = c.ops[i].layer;
@@ -178,7 +194,8 @@ __device__ __forceinline__ OpView load_op(const PCtx& c, int i) {
 }
 
 // ------------------------------------------------------------------------------------------------ loader (wave 0)
-__device__ __forceinline__ void loader_role(const PCtx& c) {
+template <class C>
+__device__ __forceinline__ void loader_role(const C& c) {
   const PersistArgs& a = *c.a;
   const unsigned ring_pieces = a.ring_bytes / kPiece;
   const unsigned voff = c.lane * 16;
@@ -304,7 +321,8 @@ __device__ __forceinline__ unsigned long long* edge_base(const PersistArgs& a, i
 __device__ __forceinline__ unsigned long long* granule_ptr(const PersistArgs& a, int layer, int edge, unsigned idx) {
   return edge_base(a, layer, edge) + granule_slot(a, idx);
 }
-__device__ __forceinline__ unsigned edge_tag(const PCtx& c, int layer, int edge) { return c.tag0 | static_cast<unsigned>(layer * 8 + edge + 1); }
+template <class C>
+__device__ __forceinline__ unsigned edge_tag(const C& c, int layer, int edge) { return c.tag0 | static_cast<unsigned>(layer * 8 + edge + 1); }
 __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned tag, unsigned value) {
   __hip_atomic_store(g, (static_cast<unsigned long long>(tag) << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -331,7 +349,8 @@ struct EpiPrep {
   unsigned* acttap;
 };
 
-__device__ __forceinline__ EpiPrep epilogue_prep(const PCtx& c, const OpView& o, int tile, int np, const LeadLane& L) {
+template <class C>
+__device__ __forceinline__ EpiPrep epilogue_prep(const C& c, const OpView& o, int tile, int np, const LeadLane& L) {
   const PersistArgs& a = *c.a;
   EpiPrep e{};
   e.valid = L.tok_ok && L.jp < np;
@@ -378,8 +397,8 @@ __device__ __forceinline__ EpiPrep epilogue_prep(const PCtx& c, const OpView& o,
 
 // dbl: the tile was multiplied two steps at a time (consume_op): real row r of the tile = MFMA rows r (even k groups, token
 // column 2 t, stored as partial row r) + r + 8 (odd k groups, column 2 t + 1, stored as partial row r + 8)
-template <int W_FIRST, bool DBL>
-__device__ __forceinline__ void epilogue_finish(const PCtx& c, const OpView& o, const EpiPrep& e, const float* part, const LeadLane& L, ConsState& st) {
+template <int W_FIRST, bool DBL, class C>
+__device__ __forceinline__ void epilogue_finish(const C& c, const OpView& o, const EpiPrep& e, const float* part, const LeadLane& L, ConsState& st) {
   const PersistArgs& a = *c.a;
   float y0 = 0.f, y1 = 0.f;
   if (e.valid) {
@@ -505,8 +524,8 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* ringp, unsigned 
   }
 }
 
-template <bool DIAG = false>
-__device__ __forceinline__ bool consume_op(const PCtx& c, int cw, const OpView& o, ConsState& st, const LeadLane& L, int ts_mfma) {
+template <bool DIAG = false, class C>
+__device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, ConsState& st, const LeadLane& L, int ts_mfma) {
   // ONE copy of this routine for the three consumers (the leader's parts under a wave-uniform branch): the launch's code must
   // stay inside the 64 KiB instruction cache two CUs share — with a copy per role (and per call site of the gathers) the
   // kernel was ~150 KiB and every phase of every wave started on instructions fetched from memory
@@ -526,7 +545,7 @@ __device__ __forceinline__ bool consume_op(const PCtx& c, int cw, const OpView& 
   const bool multi = o.n_tiles > 1;
   const bool dbl0 = !multi && o.my_pairs == 4 && (o.steps & 1) == 0;
   const int units0 = dbl0 ? o.steps >> 1 : o.steps;
-  const bool lead_in = !multi && units0 >= 96;
+  const bool lead_in = !multi && (units0 >= 96 || (SD_P_LEADQKV && o.my_pairs != 4 && o.my_pairs != 8 && units0 > kChunk));
   const int share = lead_in ? 3 : 2;
   // (when it does multiply, the leader takes the short share: chunk 2, 5, ... of a tile)
   const int first_chunk = lead_in ? (cw + 2) % 3 : cw - 1;   // -1: this wave (the leader) does not multiply in this op
@@ -633,7 +652,8 @@ __device__ __forceinline__ bool consume_op(const PCtx& c, int cw, const OpView& 
 // ---- gatherer (consumer 1): sweep granules ----------------------------------------------------------------------------
 // The staged rows of the previous op may still be read by the other two consumers' MFMAs: they are free once both have
 // handed in the partial of the op's last tile. The sweep's loads are issued BEFORE this wait.
-__device__ __forceinline__ bool wait_rows_free(const PCtx& c, const ConsState& st, int me = 1) {
+template <class C>
+__device__ __forceinline__ bool wait_rows_free(const C& c, const ConsState& st, int me = 1) {
   const int o1 = (me + 1) % 3, o2 = (me + 2) % 3;
   return wait_word<1>(c, &c.ctl->done[o1], st.tile_no, ST_PART) && wait_word<1>(c, &c.ctl->done[o2], st.tile_no, ST_PART);
 }
@@ -645,8 +665,8 @@ __device__ __forceinline__ bool wait_rows_free(const PCtx& c, const ConsState& s
 // TWO passes are kept in flight, half a round trip apart: a pass that was issued just before the last producer's granule
 // became visible comes back incomplete, and with one pass at a time the next one only starts then (a full round trip, ~1.2 us,
 // lost on most edges; measured 3.7 us from the last publish to the staged vector for an 8 KiB edge).
-template <int NC>
-__device__ __forceinline__ bool sweep(const PCtx& c, const unsigned long long* base, unsigned first, int count, unsigned tag, unsigned (&v)[NC][16]) {
+template <int NC, class C>
+__device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base, unsigned first, int count, unsigned tag, unsigned (&v)[NC][16]) {
   const PersistArgs& a = *c.a;
   const unsigned long long* p[NC][16];
 #pragma unroll
@@ -698,8 +718,8 @@ __device__ __forceinline__ bool sweep(const PCtx& c, const unsigned long long* b
 
 // input rows of a norm-fused op (QKV, GATEUP, HEAD): gather the d_model-wide rows (granules of edge `edge`, or the
 // embedding rows for layer 0), RMSNorm them (HF LlamaRMSNorm: weight * (x * rsqrt(mean(x^2) + eps)).to(bf16)), stage as bf16
-template <int HC>
-__device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts) {
+template <int HC, class C>
+__device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts) {
   const PersistArgs& a = *c.a;
   const int npt = a.d_model >> 1;   // dwords (pairs) per row
   const unsigned* nw = static_cast<const unsigned*>(o.norm_w);
@@ -762,8 +782,8 @@ __device__ __forceinline__ bool gather_norm_rows(const PCtx& c, const OpView& o,
 }
 
 // input rows taken as they are (attention rows for the out-projection, activations for the down-projection)
-template <int NC>
-__device__ __forceinline__ bool gather_plain_chunks(const PCtx& c, const unsigned long long* g, unsigned first, int count, unsigned tag, unsigned* dst,
+template <int NC, class C>
+__device__ __forceinline__ bool gather_plain_chunks(const C& c, const unsigned long long* g, unsigned first, int count, unsigned tag, unsigned* dst,
                                                     int dst0, bool& first_write, const ConsState& st, int me) {
   unsigned v[NC][16];
   if (!sweep<NC>(c, g, first, count, tag, v)) return false;
@@ -780,7 +800,8 @@ __device__ __forceinline__ bool gather_plain_chunks(const PCtx& c, const unsigne
 }
 
 // granules [lo, hi) of every token row (npt per row); wave `me` of the three consumers does the sweeping
-__device__ __forceinline__ bool gather_plain_rows(const PCtx& c, int layer, int edge, int npt, int lo, int hi, const ConsState& st, int me) {
+template <class C>
+__device__ __forceinline__ bool gather_plain_rows(const C& c, int layer, int edge, int npt, int lo, int hi, const ConsState& st, int me) {
   const PersistArgs& a = *c.a;
   const unsigned tag = edge_tag(c, layer, edge);
   const unsigned long long* g = edge_base(a, layer, edge);
@@ -808,8 +829,8 @@ constexpr int kSplitSweep = SD_P_SPLIT;
 // The gatherer sweeps q / new k / new v of the unit; every wave has the K / V operands of its first cached block in flight
 // before it waits for them; the cached 32-key blocks go round-robin over the waves, the block of the M new positions (from
 // LDS) to the wave whose turn it is; the leader merges the three partials and publishes the rows.
-template <int D>
-__device__ __forceinline__ bool attention_unit(const PCtx& c, int cw, int layer, int b, int h, ConsState& st, int ts) {
+template <int D, class C>
+__device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, int b, int h, ConsState& st, int ts) {
   const PersistArgs& a = *c.a;
   constexpr int NKS = D / 32, NDT = D / 16;
   const int lane = c.lane, g = lane >> 4, n = lane & 15;
@@ -1052,8 +1073,8 @@ __device__ __forceinline__ int unit_of_cu(int cu, int n_units) {
   return (u < n_units && home == cu) ? u : -1;
 }
 
-template <int D, int HC>
-__device__ __forceinline__ void consumer_role(const PCtx& c, int cw) {
+template <int D, int HC, class C>
+__device__ __forceinline__ void consumer_role(const C& c, int cw) {
   const PersistArgs& a = *c.a;
   const int lane = c.lane;
   ConsState st{};
@@ -1115,6 +1136,17 @@ __device__ __forceinline__ void consumer_role(const PCtx& c, int cw) {
         const bool emb = (o.kind == POP_QKV && o.layer == 0) || (o.kind == POP_HEAD && a.n_layers == 0);
         ok = gather_norm_rows<HC>(c, o, edge, emb, st, 12 * i);
       }
+    } else if (SD_P_SPLIT3 && ((o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1) > kSplitSweep) {
+      const int edge = (o.kind == POP_OUT) ? PE_ATTN : PE_ACT;
+      const int npt = (o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1;
+      const int third = (npt / 3) & ~63;
+      const int lo = (cw == 1) ? 0 : (cw == 2 ? third : 2 * third), hi = (cw == 1) ? third : (cw == 2 ? 2 * third : npt);
+      ok = gather_plain_rows(c, o.layer, edge, npt, lo, hi, st, cw);
+      if (ok) {
+        if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
+        else if (cw == 0) lds_st(&c.ctl->g3_seq, static_cast<unsigned>(i + 1));
+        else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ) && wait_word<1>(c, &c.ctl->g3_seq, static_cast<unsigned>(i + 1), ST_USEQ);
+      }
     } else if (cw != 0) {
       const int edge = (o.kind == POP_OUT) ? PE_ATTN : PE_ACT;
       const int npt = (o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1;
@@ -1159,7 +1191,7 @@ __device__ __forceinline__ void consumer_role(const PCtx& c, int cw) {
   }
 }
 
-template <int D, int HC>
+template <int D, int HC, bool STAMPS>
 __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
@@ -1170,7 +1202,7 @@ __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs 
   for (int i = tid; i < 4 * D; i += 256) reinterpret_cast<unsigned*>(smem + a.lds_attn + 2 * a.M * D * 2)[i] = 0u;
   const unsigned launch = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  PCtx c;
+  PCtxT<STAMPS> c;
   c.a = &a;
   c.smem = smem;
   c.ctl = reinterpret_cast<PCtl*>(smem);
@@ -1182,10 +1214,10 @@ __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs 
   c.ops = (cops_t)a.ops;
   // diagnostic: the shader clock this launch ran at = delta s_memtime / delta s_memrealtime x 100 MHz (leader of every CU)
   unsigned long long clk0 = 0;
-  if (a.debug_ts && wave == 1) clk0 = __builtin_amdgcn_s_memtime();
+  if (STAMPS && a.debug_ts && wave == 1) clk0 = __builtin_amdgcn_s_memtime();
   if (wave == 0) loader_role(c);
   else consumer_role<D, HC>(c, wave - 1);
-  if (a.debug_ts && wave == 1 && c.lane == 0) {
+  if (STAMPS && a.debug_ts && wave == 1 && c.lane == 0) {
     unsigned long long* d = a.debug_ts + static_cast<size_t>(c.cu) * (12 * a.n_ops + 4) + 12 * a.n_ops;
     d[0] = c.t_start;
     d[1] = clk0;
@@ -1272,17 +1304,21 @@ size_t persist_workspace_bytes(const sd_model_config& c) {
   return n;
 }
 
-template <int D, int HC>
-static int launch_one(const PersistArgs& a, size_t smem, hipStream_t st) {
+template <int D, int HC, bool STAMPS>
+static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(kLdsBytes)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((persist_forward_kernel<D, HC>), dim3(kPersistCUs), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS>), dim3(kPersistCUs), dim3(256), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
+}
+template <int D, int HC>
+static int launch_one(const PersistArgs& a, size_t smem, hipStream_t st) {
+  return a.debug_ts ? launch_inst<D, HC, true>(a, smem, st) : launch_inst<D, HC, false>(a, smem, st);
 }
 
 int launch_persist_forward(PersistArgs a, hipStream_t st) {

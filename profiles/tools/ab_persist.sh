@@ -9,7 +9,7 @@ OBJS=$(ls llm-inference-lab_amd/csrc/.obj/*.o | grep -v "/persist\.")
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   mkdir -p _ab_$name
-  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -Iinclude $flags -x hip -c llm-inference-lab_amd/csrc/persist.hip -o _ab_$name/persist.o
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -Iinclude $flags -x hip -c ${PERSIST_SRC:-llm-inference-lab_amd/csrc/persist.hip} -o _ab_$name/persist.o
   hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc $OBJS _ab_$name/persist.o -o _ab_$name/libspecdec_hip.so
   echo "built _ab_$name ($flags)"
 done
