@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--target", default="llama-3.2-3b")
     ap.add_argument("--draft", default="llama-3.2-1b")
     ap.add_argument("--flip", type=float, default=0.2, help="fraction of tokens whose draft successor differs")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=2,
+    ap.add_argument("--cpu-baseline-steps", type=int, default=4,
                     help="steps per timed repeat of the CPU baseline leg (1 warm-up step + 3 repeats); 0 disables the leg")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--weight-dtype", choices=["bf16", "fp8"], default="bf16",
@@ -133,7 +133,7 @@ def cpu_threads():
     return min(visible, 16), f"min(affinity mask {visible}, 16-CPU share of a 1-GPU box)"
 
 
-def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=2, repeats=3):
+def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=4, repeats=3):
     """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample (SURVEY section 8d protocol:
     one warm-up, >= 3 timed repeats, median; CPU model and thread count stated).
       L0 = 32 (the GPU run's prompt 0): ONE run of 1 + repeats * seg_steps steps; step 1 is the warm-up, every following
@@ -178,6 +178,7 @@ def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=
     res_l, med_l, rates_l, wall_l = run(long_prompt, 1)
     return {
         "value": med, "unit": "tokens/s", "cores": threads, "kind": "port",
+        "min": min(rates), "median": med, "max": max(rates),
         "cpu_model": cpu_model_string(), "threads_source": how,
         "sample": f"prompt 0 (L0={PROMPT_LEN}), reference-faithful loop (2K full-prefix forwards per step, bf16-rounded weights / activations, fp32 "
                   f"accumulation): 1 warm-up step, then {repeats} repeats of {seg_steps} steps each, median of the per-repeat rates "
@@ -259,47 +260,62 @@ def roofline_leg(sess, B, K, wd, self_draft):
     cand = []   # (label, model, which, T, launches per step)
     names = {tm.PROBE_O: ("o_proj", "EPI_RESID"), tm.PROBE_GATE_UP: ("norm+gate/up+SwiGLU", "EPI_SWIGLU"), tm.PROBE_DOWN: ("down", "EPI_RESID"),
              tm.PROBE_LM_HEAD: ("norm+lm_head+argmax", "EPI_ARGMAX")}
+    # passes of <= persist_t tokens of the draft run as ONE persistent launch (csrc/persist.hip): their GEMV launches do not exist
+    persist_t = dm.persist_tokens if dm is not None else 0
     for which in (tm.PROBE_O, tm.PROBE_GATE_UP, tm.PROBE_DOWN, tm.PROBE_LM_HEAD):
         n = 1 if which == tm.PROBE_LM_HEAD else tm.cfg.n_layers
         cand.append(("target", tm, which, Tt, n))
         if dm is not None:
             nd = (1 if which == dm.PROBE_LM_HEAD else dm.cfg.n_layers)
-            cand.append(("draft", dm, which, min(B, dm.pass_tokens), nd * (K - 1)))       # draft forwards 2..K: one token per row
-            cand.append(("draft", dm, which, min(2 * B, dm.pass_tokens), nd))             # draft forward 1: (prev, last)
+            if B > persist_t:
+                cand.append(("draft", dm, which, min(B, dm.pass_tokens), nd * (K - 1)))       # draft forwards 2..K: one token per row
+            if 2 * B > persist_t:
+                cand.append(("draft", dm, which, min(2 * B, dm.pass_tokens), nd))             # draft forward 1: (prev, last)
     rows = []
     for who, m, which, T, n in cand:
         u, nb = m.probe_gemv(which, T=T, iters=200 if which != m.PROBE_LM_HEAD else 60, stream=st)
-        kname = "gemv_mfma_kernel" if T <= 9 else "gemm_skinny_kernel"
+        # (> 9 tokens: launch_gemm_skinny picks one of four bodies per shape — pipe, slice, direct or the chunked fallback)
+        kname = "gemv_mfma_kernel" if T <= 9 else "gemm_pipe/slice/direct/skinny_kernel"
         rows.append({"kernel": f"{kname}<{names[which][1]}> ({who} {names[which][0]}, {T} token{'s' if T > 1 else ''})", "who": who, "which": which,
                      "T": T, "launches_per_step": n, "avg_launch_us": u, "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9,
                      "us_per_step": n * u})
+    if dm is not None and persist_t >= B and B == 1:
+        # the whole 1-token draft forward (embedding, layers, lm_head, argmax partials) is one kernel; timed at a context of
+        # prompt + 32 positions; its algorithmic bytes = every matmul weight of the draft once
+        n_fw = (K - 1) + (1 if 2 * B <= persist_t else 0)
+        u, nb, _ = dm.probe_forward(M=1, iters=40, pos0=PROMPT_LEN + 32, stream=st)
+        c = dm.cfg
+        rows.append({"kernel": f"persist_forward_kernel<{c.head_dim}, {1 if c.d_model <= 2048 else 2}, false> (draft forward, 1 token: {c.n_layers} layers + "
+                               "lm_head as ONE launch)", "who": "draft", "which": -1, "T": 1, "launches_per_step": n_fw, "avg_launch_us": u,
+                     "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9, "us_per_step": n_fw * u})
     top = max(rows, key=lambda r: r["us_per_step"])
     ach = top["GBps"]
     roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
             "frac": ach * 1e9 / HBM_PEAK_BPS, "traffic": None, "bytes_per_launch": top["bytes_per_launch"],
             "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"], "us_per_step": top["us_per_step"],
-            "selection": "the GEMV with the largest (launches per step x average launch time), all timed in this run"}
+            "selection": "the weight-streaming kernel with the largest (launches per step x average launch time), all timed in this run"}
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE x2 on
     # gfx950; profiles/summarize.py): counters cannot be read from inside this process, so the figure comes from the
     # committed summary — and only when that summary was taken with THIS build of the library (content hash)
-    pmc = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
-    epi = {tm.PROBE_O: 1, tm.PROBE_GATE_UP: 2, tm.PROBE_DOWN: 1, tm.PROBE_LM_HEAD: 4}[top["which"]]
+    pmc = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
+    epi = {tm.PROBE_O: 1, tm.PROBE_GATE_UP: 2, tm.PROBE_DOWN: 1, tm.PROBE_LM_HEAD: 4, -1: -1}[top["which"]]
     tt = next(t for t in (1, 2, 3, 5, 9) if top["T"] <= t) if top["T"] <= 9 else None
     if os.path.exists(pmc) and tt is not None and wd == "bf16":
         with open(pmc) as f:
             tj = json.load(f)
         meta = tj.get("_meta", {})
         if meta.get("lib_sha256") != lib_sha256():
-            roof["traffic_note"] = "profiles/round2_pmc_traffic.json was taken with another build of libspecdec_hip.so: not quoted"
+            roof["traffic_note"] = "profiles/round3_pmc_traffic.json was taken with another build of libspecdec_hip.so: not quoted"
         elif meta.get("workload") != f"{sess.pipe.base_lm.model_name}+{'' if self_draft else sess.pipe.draft_lm.model_name} K={K} B={B}":
-            roof["traffic_note"] = f"profiles/round2_pmc_traffic.json is for {meta.get('workload')!r}: not quoted"
+            roof["traffic_note"] = f"profiles/round3_pmc_traffic.json is for {meta.get('workload')!r}: not quoted"
         else:
             # gate/up and down differ in bytes per launch: pick the entry of this epilogue and token bucket whose bytes are nearest
-            ks = [(k, v) for k, v in tj.items() if k.startswith(f"gemv_mfma_kernel<{epi}, false, {tt}, false")]
+            prefix = "persist_forward_kernel<" if epi == -1 else f"gemv_mfma_kernel<{epi}, false, {tt}, false"
+            ks = [(k, v) for k, v in tj.items() if k.startswith(prefix)]
             if ks:
                 k_, t = min(ks, key=lambda kv: abs(kv[1]["hbm_bytes_per_launch"] - top["bytes_per_launch"]))
                 roof["traffic"] = t["hbm_bytes_per_launch"]
-                roof["traffic_source"] = f"profiles/round2_pmc_traffic.json [{k_}] (rocprofv3 --pmc passes of bench.py, same library build)"
+                roof["traffic_source"] = f"profiles/round3_pmc_traffic.json [{k_}] (rocprofv3 --pmc passes of bench.py, same library build)"
     roof["other_kernels"] = {r["kernel"]: {k: r[k] for k in ("avg_launch_us", "GBps", "launches_per_step", "us_per_step")} for r in rows if r is not top}
     return roof
 
@@ -315,10 +331,12 @@ def dry_run(args, world, rank):
 
         dist.init_process_group("gloo")
         dist.barrier()
-    job = gather_stats({"tokens": rank + 1, "proposed": 4, "accepted": 1, "accepted_strict": 0, "wall_ns": 10 ** 9, "steps": 1},
-                       torch.device("cpu"))
+    job = gather_stats({"tokens": rank + 1, "proposed": 4, "accepted": 1, "accepted_strict": 0, "wall_ns": 10 ** 9 + rank, "steps": 1,
+                        "numa_node": rank % 2, "cpus": len(os.sched_getaffinity(0))}, torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": int(job.per_rank.shape[0]), "tokens": job.total("tokens"), "value": None}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": int(job.per_rank.shape[0]), "tokens": job.total("tokens"), "value": None,
+                          "ranks": {"ms_per_step_min": min(job.column("wall_ns")) / 1e6, "ms_per_step_max": max(job.column("wall_ns")) / 1e6,
+                                    "numa_node": job.column("numa_node"), "cpus": job.column("cpus")}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -435,7 +453,9 @@ def main():
 
     # the one collective of the job: a 48-byte struct per rank, all-gathered over RCCL/xGMI
     job = gather_stats({"tokens": n_tok, "proposed": proposed, "accepted": accepted_ref,
-                        "accepted_strict": accepted_strict, "wall_ns": int(dt_local * 1e9), "steps": args.steps}, stats_device)
+                        "accepted_strict": accepted_strict, "wall_ns": int(dt_local * 1e9), "steps": args.steps,
+                        "numa_node": -1 if numa.get("numa_node") is None else numa["numa_node"],
+                        "cpus": len(os.sched_getaffinity(0))}, stats_device)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -457,7 +477,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if wd == "bf16" else "bf16 MFMA over fp8-e4m3 weight storage", "data": "synthetic",
         "config": {"workload": f"{args.target} target + {args.draft} draft, K={K}, batch {B}/GPU, {'sampled bonus token T=0.7 top_k=50 top_p=0.9' if args.do_sample else 'greedy'}{(', EAGLE-lite hidden-state extrapolation (self-draft), generate() loop' if args.draft_mode == 'eagle' else ', Medusa-lite tied heads (self-draft), generate() loop') if medusa else ''}{', persistent Medusa heads (synthetic)' if heads is not None else ''}, "
-                               f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}",
+                               f"prompt {PROMPT_LEN} ids, hipGraph step, weights: {source}"
+                               + (" (BASELINE config 4's per-GPU shape: 32 rows over 8 GPUs)" if args.target == "llama-3-8b" and B == 4 and not medusa else ""),
                    "K": K, "batch_per_gpu": B, "global_batch": B * world, "prompt_len": PROMPT_LEN,
                    "parallelism": f"dp{world}"},
         "acceptance_rate": job.acceptance(),                 # reference definition: bonus token counted
@@ -466,6 +487,10 @@ def main():
         "step_bytes": bytes_step,
         "step_roofline_frac": bytes_step / (ms_per_step / 1e3) / HBM_PEAK_BPS,
         "resyncs": sess.stats["resyncs"],
+        # per rank: time per step (the job's figure is the slowest rank's), the NUMA node its threads were pinned to (-1: the
+        # box gave no answer, mask left alone) and the CPUs left in its affinity mask (>= 1 by construction)
+        "ranks": {"ms_per_step_min": min(job.column("wall_ns")) / 1e6 / args.steps, "ms_per_step_max": max(job.column("wall_ns")) / 1e6 / args.steps,
+                  "numa_node": job.column("numa_node"), "cpus": job.column("cpus")},
         "rank0_numa": numa, "collective_backend": ("gloo (rehearsal: all ranks on cuda:0)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
         # one-off H2D of the prompt ids of this rank's rows, measured, and the rate with it added to the timed region
         "h2d_prompt_us": h2d_s * 1e6,

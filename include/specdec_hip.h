@@ -426,6 +426,7 @@ int sd_specdec_sync(sd_specdec* s, void* stream);
  *   [4+K .. 3+2K]         draft tokens d_1..d_K
  *   [4+2K .. 4+3K]        target argmax t_0..t_K
  *   [5+3K]                proposals that counted for the row in this step (K unless sd_specdec_set_adaptive)
+ *   [6+3K]                health word of the models' persistent launches (sd_model_engine_status), 0 = all completed
  * row stride = sd_specdec_record_ints(). */
 const int32_t* sd_specdec_record(const sd_specdec* s);
 int sd_specdec_record_ints(const sd_specdec* s);

@@ -233,14 +233,9 @@ __device__ __forceinline__ void attention_tile(const AttnArgs& a, int kvh, int b
     // per workgroup fences: an agent-scope fence is a cache-wide L2 write-back / invalidate on this part (with every
     // thread fencing 8 K / 32 K contexts took 6.34 / 8.63 ms per step; this form 5.66 / 7.09). The partial tiles
     // themselves still move with agent-scope relaxed atomics (write-through stores, L2-bypassing loads), which leaves
-    // the fences nothing to write back. Building with -DSD_ATTN_FENCE_FREE drops the release / acquire and relies on
-    // s_waitcnt + the barriers alone (gfx950 behaviour, not a memory-model guarantee: 5.6 / 6.89 ms; experiments only).
-#ifdef SD_ATTN_FENCE_FREE
-    __builtin_amdgcn_s_waitcnt(0);
-    constexpr int kArrive = __ATOMIC_RELAXED;
-#else
+    // the fences nothing to write back. (Measured once and not kept: dropping the release / acquire and relying on s_waitcnt
+    // + the barriers alone — gfx950 behaviour, not a memory-model guarantee — 5.6 / 6.89 ms.)
     constexpr int kArrive = __ATOMIC_ACQ_REL;
-#endif
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(m_s);  // LDS scratch (m_s is dead after the loop above)
     if (tid == 0) {

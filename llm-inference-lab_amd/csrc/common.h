@@ -14,11 +14,7 @@
 namespace sd {
 
 // scalar kernel arguments made live at one point (see pin_gemv_args, gemv_device.h): the s_loads are issued back to back
-#ifndef SD_NO_PIN_ARGS
 #define SD_PIN(...) asm volatile("" ::__VA_ARGS__)
-#else
-#define SD_PIN(...)
-#endif
 
 // Per-row adaptive K (sd_specdec_set_adaptive): launches of draft forward i >= 1 are in the captured step for every
 // i < K, but when no row proposes more than *k_active tokens the ones with i >= *k_active leave at once (one scalar

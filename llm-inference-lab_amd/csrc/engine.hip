@@ -398,6 +398,10 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
   SD_REQUIRE(cfg->d_model % 8 == 0 && cfg->d_ff % 8 == 0 && (cfg->n_heads * cfg->head_dim) % 8 == 0,
              "model_create: d_model, d_ff and Hq*D must be multiples of 8");
   SD_REQUIRE(cfg->head_dim % 2 == 0 && cfg->n_heads % cfg->n_kv_heads == 0, "model_create: head layout");
+  // the kernels' argument blocks carry these in 8-bit fields (GemvArgs / AttnArgs), and the attention kernel is instantiated
+  // for these head sizes only: a direct C caller gets an error, not a truncated geometry
+  SD_REQUIRE(cfg->n_heads <= 255 && cfg->n_kv_heads <= 255, "model_create: at most 255 heads (got %d / %d kv)", cfg->n_heads, cfg->n_kv_heads);
+  SD_REQUIRE(cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128, "model_create: head_dim %d (32, 64 or 128)", cfg->head_dim);
   SD_REQUIRE(cfg->tok_emb && cfg->lm_head && cfg->final_norm_w && cfg->layers, "model_create: NULL weights");
   if (cfg->arch == SD_ARCH_LLAMA) SD_REQUIRE(cfg->rope_cos && cfg->rope_sin, "model_create: Llama needs rope tables");
   if (cfg->arch == SD_ARCH_GPT2) SD_REQUIRE(cfg->pos_emb && cfg->final_norm_b, "model_create: GPT-2 needs pos_emb and ln_f bias");
@@ -876,7 +880,8 @@ namespace sd {
 // The step record, written straight into pinned host memory (device-accessible). Two slots, selected by the parity
 // of a device-resident step counter, so that the host can still read step s while step s+1 (launched ahead) writes
 // its own. One wave walks the rows, then advances the counter.
-__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec_slots, int rec_ints, int32_t* step_counter) {
+__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec_slots, int rec_ints, int32_t* step_counter,
+                                                            const unsigned* draft_status, const unsigned* target_status) {
   const int lane = threadIdx.x;
   const int K = s.K;
   const int slot = *step_counter & 1;
@@ -894,6 +899,8 @@ __global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t
     }
     if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
     if (lane == 0) r[5 + 3 * K] = s.adaptive ? s.ctl[4 * b + 3] : K;   // proposals that counted for the row in this step
+    // health of the persistent launches (sd_model_engine_status): non-zero = a launch of this or an earlier step gave up
+    if (lane == 0) r[6 + 3 * K] = static_cast<int32_t>((draft_status ? *draft_status : 0u) | (target_status ? *target_status : 0u));
   }
   if (s.adaptive) {   // widest row of the next step
     int ka = 0;
@@ -1031,7 +1038,8 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
       return rc;
   }
   if (int rc = launch_accept(s->st, s->mode, s->sample, st_t)) return rc;
-  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(kWave), 0, st_t, s->st, s->host_record, s->rec, s->step_counter);
+  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(kWave), 0, st_t, s->st, s->host_record, s->rec, s->step_counter,
+                     (s->draft && s->draft->p_sync) ? s->draft->p_sync + 1 : nullptr, s->target->p_sync ? s->target->p_sync + 1 : nullptr);
   SD_LAUNCH_CHECK();
   // persistent Medusa heads: the proposals of the next step, after the record of this one has left
   if (!s->heads.empty())
@@ -1057,7 +1065,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   s->B = B;
   s->K = K;
   s->mode = emit_mode;
-  s->rec = 6 + 3 * K;
+  s->rec = 7 + 3 * K;
   const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1) + 1);
   const size_t n_adapt = static_cast<size_t>(B) * (1 + 4 + 8) + 2 + 2;   // k_row, ctl, ctl_hist (doubles), k_active (+ alignment)
   const size_t n_total = n_state + 4 + n_adapt;

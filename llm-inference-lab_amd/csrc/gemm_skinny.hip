@@ -830,20 +830,30 @@ static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, 
   return a.w8 ? launch_skinny_w<EPI, true>(a, sg, grid, smem, st) : launch_skinny_w<EPI, false>(a, sg, grid, smem, st);
 }
 
-// mirrors the dispatch of launch_gemm_skinny for an EPI_RESID launch: direct, slice and pipe kernels publish the row
-// statistics (xstat_out), the chunked fallback below does not
+// Which body a multi-token launch takes — ONE function, used by the launcher and by the forward's question "does this
+// EPI_RESID launch publish the row statistics" (a second copy of these conditions would let the two drift apart: the
+// consumer would then fold stale partial sums with no error). The knobs are read once.
+enum SkinnyBody { BODY_DIRECT, BODY_SLICE, BODY_PIPE, BODY_CHUNKED };
+static SkinnyBody choose_skinny_body(const GemvArgs& a, const GemvGeom& q, int epi) {
+  static const bool no_direct = getenv("SPECDEC_NO_DIRECT") != nullptr;
+  static const bool no_pipe = getenv("SPECDEC_NO_PIPE") != nullptr;
+  static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
+  const int TG = (a.T + 15) / 16;
+  const bool plain_resid = !a.w8 && a.prologue == PRO_NONE && epi == EPI_RESID;
+  // un-normalised, single-round shapes (out / down projections): operands straight to registers (measured on the 3B shapes:
+  // ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads touch 16 rows x 64 bytes per instruction)
+  if (TG == 1 && plain_resid && q.n_tiles <= kGemvWaves / q.ksplit && !no_direct) return BODY_DIRECT;
+  // ... and from 17 tokens the wave-private staging (SPECDEC_SLICE_MIN_T moves the hand-over for experiments)
+  if (a.T >= slice_min_t && a.T <= 48 && plain_resid && slice_covers(a, q, TG)) return BODY_SLICE;
+  // the statically scheduled chunk pipeline (gemm_pipe.hip) for everything else up to 64 tokens
+  if (!no_pipe && a.T <= 64 && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return BODY_PIPE;
+  return BODY_CHUNKED;
+}
+
+// direct, slice and pipe bodies publish the row statistics of an EPI_RESID launch (xstat_out), the chunked fallback does not
 bool gemm_resid_publishes_stats(const GemvArgs& a) {
   if (a.T <= kGemvMaxT || a.T > 64 || a.x_row) return false;
-  const GemvGeom q = gemv_geometry(a.n_pairs, a.K);
-  const int TG = (a.T + 15) / 16;
-  const bool single_round = q.n_tiles <= kGemvWaves / q.ksplit;
-  if (TG == 1 && !a.w8 && a.prologue == PRO_NONE && single_round && !getenv("SPECDEC_NO_DIRECT")) return true;
-  static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
-  if (a.T >= slice_min_t && a.T <= 48 && !a.w8 && a.prologue == PRO_NONE) {
-    GemvArgs b = a;
-    if (slice_covers(b, q, TG)) return true;
-  }
-  return !getenv("SPECDEC_NO_PIPE") && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0);
+  return choose_skinny_body(a, gemv_geometry(a.n_pairs, a.K), EPI_RESID) != BODY_CHUNKED;
 }
 
 bool gemm_skinny_covers(int T, int n_pairs, int K, bool w8) {
@@ -873,22 +883,11 @@ int launch_gemm_skinny(const GemvArgs& a_in, int epi, hipStream_t st) {
   sg.sc_shift = 0;
   while ((1 << sg.sc_shift) < sc) ++sg.sc_shift;
   const int TG = skinny_tg(a.T);
-  // un-normalised, single-round shapes (out / down projections): operands straight to registers
-  // (measured on the 3B shapes: ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads
-  // touch 16 rows x 64 bytes per instruction)
-  if (TG == 1 && !a.w8 && a.prologue == PRO_NONE && q.n_tiles <= kGemvWaves / q.ksplit && !getenv("SPECDEC_NO_DIRECT")) {
-    if (epi == EPI_RESID) return launch_direct<EPI_RESID>(a, q.grid, st);
-  }
-  // ... and from 17 tokens the wave-private staging (SPECDEC_SLICE_MIN_T moves the hand-over for experiments)
-  {
-    static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
-    if (a.T >= slice_min_t && a.T <= 48 && !a.w8 && a.prologue == PRO_NONE && epi == EPI_RESID && slice_covers(a, q, (a.T + 15) / 16))
-      return launch_slice<EPI_RESID>(a, q.grid, st);
-  }
-  // the statically scheduled chunk pipeline (gemm_pipe.hip) for everything else up to 64 tokens
-  {
-    static const bool no_pipe = getenv("SPECDEC_NO_PIPE") != nullptr;
-    if (!no_pipe && a.T <= 64 && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return launch_gemm_pipe(a, q, epi, st);
+  switch (choose_skinny_body(a, q, epi)) {
+    case BODY_DIRECT: return launch_direct<EPI_RESID>(a, q.grid, st);
+    case BODY_SLICE: return launch_slice<EPI_RESID>(a, q.grid, st);
+    case BODY_PIPE: return launch_gemm_pipe(a, q, epi, st);
+    default: break;
   }
   const size_t smem = skinny_smem(a.T, TG, sg.kc);
   switch (epi) {

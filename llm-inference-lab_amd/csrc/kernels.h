@@ -13,6 +13,7 @@ enum GemvEpilogue { EPI_QKV_ROPE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 
 
 constexpr int kGemvMaxT = 9;     // tokens per launch of gemv.hip (K+1 for K = 8)
 constexpr int kSkinnyMaxT = 128; // tokens per launch of gemm_skinny.hip (batched verify, chunked prefill)
+static_assert(kSkinnyMaxT <= 255, "GemvArgs::T / M are 8-bit fields");
 
 struct GemvArgs {
   // Field ORDER and WIDTHS are part of the design: these kernels are latency chains, every launch starts by pulling its

@@ -289,7 +289,7 @@ class HipModel:
 class StepRecord:
     """Host view of one completed step (pinned memory written by the device)."""
 
-    __slots__ = ("accept_len", "n_new", "cur_len", "new_tokens", "draft_tokens", "target_ids", "k_row")
+    __slots__ = ("accept_len", "n_new", "cur_len", "new_tokens", "draft_tokens", "target_ids", "k_row", "engine_status")
 
     def __init__(self, arr: np.ndarray, K: int):
         self.accept_len = arr[:, 0].copy()
@@ -299,6 +299,11 @@ class StepRecord:
         self.draft_tokens = arr[:, 4 + K:4 + 2 * K].copy()
         self.target_ids = arr[:, 4 + 2 * K:5 + 3 * K].copy()
         self.k_row = arr[:, 5 + 3 * K].copy()      # proposals that counted per row (per-row adaptive K), else K
+        # health word of the models' persistent launches (sd_model_engine_status): a launch that gave up leaves garbage
+        self.engine_status = int(arr[0, 6 + 3 * K]) if arr.shape[1] > 6 + 3 * K else 0
+        if self.engine_status:
+            raise _abi.HipLibraryError(f"a persistent forward gave up (status {self.engine_status:#x}: see sd_model_engine_status); "
+                                       "the step's outputs are invalid")
 
 
 class HipSpecDec:

@@ -107,11 +107,10 @@ class SpeculativePipeline:
         if mode == "medusa" and medusa_heads is not None:
             pass
         elif mode == "medusa":
-            # Medusa-lite as the reference's draftor defines it (modes/medusa.py): heads tied to / copied from the
-            # lm_head, head 0 evaluated on the same last hidden state for all K proposals -> K copies of the
-            # target's own next token. The pipeline's HF path re-creates RANDOM heads on every call
-            # (pipeline.py:689-705), which has no reproducible restatement; `head_init: random` is refused.
-            # `head_init: random` is what the reference PIPELINE runs for every Medusa configuration (_run_medusa_hf,
+            # `head_init: tie` / `copy`: Medusa-lite as the reference's draftor defines it (modes/medusa.py): heads tied to /
+            # copied from the lm_head, head 0 evaluated on the same last hidden state for all K proposals -> K copies of the
+            # target's own next token.
+            # `head_init: random`: what the reference PIPELINE runs for every Medusa configuration (_run_medusa_hf,
             # pipeline.py:655-763: fresh nn.Linear heads with normal_(0, 0.02) weights and multinomial draws from the global
             # torch generator on every step): _draft_medusa_random below, generate() only.
             if self.config.get("medusa", {}).get("head_init", "tie") not in ("tie", "copy", "random"):
@@ -379,12 +378,14 @@ class SpeculativePipeline:
         for lm in (self.base_lm, self.draft_lm):
             if lm is not None:
                 lm.clear_kv_cache()
-        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "accepted_draft": 0, "device_ms": 0.0, "void_row_steps": 0}
         step = 0
         while any(r.active for r in rows):
             step += 1
+            # the controller sees the STRICT rate (accepted draft tokens / proposed, <= 1): the reported `accepted` counts the
+            # bonus / correction token as generate_batch does and would read (k+1)/k on a fully accepted step
             ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
-                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+                   "acceptance_rate": stats["accepted_draft"] / max(stats["proposed"], 1)}
             k = int(self.controller.get_k(step, ctx))
             if k <= 0:
                 break
@@ -460,6 +461,7 @@ class SpeculativePipeline:
                 if eos is not None and eos in emitted:
                     emitted = emitted[: emitted.index(eos) + 1]
                     r.active = False
+                emitted = emitted[: max(max_tokens - len(r.generated), 0)]   # this path is the product's own: no overshoot of the budget
                 r.seq = r.seq + emitted
                 r.generated.extend(emitted)
                 r.proposed += k
@@ -467,6 +469,7 @@ class SpeculativePipeline:
                 r.steps += 1
                 stats["proposed"] += k
                 stats["accepted"] += a + 1
+                stats["accepted_draft"] += a
                 if len(r.generated) >= max_tokens or r.steps >= step_limit:
                     r.active = False
         torch.cuda.synchronize()

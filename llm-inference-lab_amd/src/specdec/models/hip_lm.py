@@ -250,9 +250,29 @@ class HipLM(LanguageModel):
         if m is None or not self._cached or not self._cached[0]:
             return None
         n = len(self._cached[0])
-        k, v = m.kv_view()  # k [L,B,H,Lmax,D], v [L,B,H,D,Lmax]
-        kv = tuple((k[l, :, :, :n, :], v[l, :, :, :, :n].transpose(-1, -2)) for l in range(self.config.n_layers))
-        return KVCache(past_key_values=kv, seq_len=n, dtype=torch.bfloat16, device=self._device)
+        k, v = m.kv_view()
+        if m.page_len is None:   # dense rows: k [L,B,H,Lmax,D], v [L,B,H,D,Lmax] -> views
+            kv = tuple((k[l, :, :, :n, :], v[l, :, :, :, :n].transpose(-1, -2)) for l in range(self.config.n_layers))
+            return KVCache(past_key_values=kv, seq_len=n, dtype=torch.bfloat16, device=self._device)
+        # paged engine: k [L,pages,H,P,D], v [L,pages,H,D,P]; a row's positions are spread over the pages it owns
+        # (HipModel._owned, in position order) -> gather them into dense [B,H,n,D] copies
+        P = m.page_len
+        need = (n + P - 1) // P
+        rows = []
+        for b in range(len(self._cached)):
+            own = m._owned[b][:need]
+            if len(own) < need:
+                raise RuntimeError(f"get_kv_cache: row {b} owns {len(own)} pages, {need} needed for {n} positions")
+            rows.append(torch.tensor(own, dtype=torch.long, device=self._device))
+        idx = torch.stack(rows, 0)                                   # [B, need]
+        kv = []
+        for l in range(self.config.n_layers):
+            kl = k[l].index_select(0, idx.reshape(-1)).view(idx.shape[0], need, *k.shape[2:])      # [B,need,H,P,D]
+            vl = v[l].index_select(0, idx.reshape(-1)).view(idx.shape[0], need, *v.shape[2:])      # [B,need,H,D,P]
+            kd = kl.permute(0, 2, 1, 3, 4).reshape(idx.shape[0], k.shape[2], need * P, k.shape[4])[:, :, :n, :]
+            vd = vl.permute(0, 2, 1, 4, 3).reshape(idx.shape[0], v.shape[2], need * P, v.shape[3])[:, :, :n, :]
+            kv.append((kd, vd))
+        return KVCache(past_key_values=tuple(kv), seq_len=n, dtype=torch.bfloat16, device=self._device)
 
     def get_last_generated_kv(self) -> Optional[KVCache]:
         return self._last_generated_kv
@@ -265,6 +285,10 @@ class HipLM(LanguageModel):
     def clear_kv_cache(self) -> None:
         self._cached = [[] for _ in self._cached]
         self._last_generated_kv = None
+        m = self._model
+        if m is not None and m.page_len is not None:   # paged engine: the rows' pages go back to the pool
+            for b in range(m.batch):
+                m.release(b)
 
     def optimize(self, *a, **k):
         return self

@@ -58,8 +58,10 @@ def main(argv=None) -> int:
                                                        ("target_acceptance_rate", args.target_acceptance)) if v is not None}
         if args.per_row_K:
             cp["per_row"] = True
-            if args.max_k is not None and "initial_k" not in cp:
-                cp["initial_k"] = min(4, args.max_k)
+            # the device controller requires min_k <= initial_k <= max_k (sd_specdec_set_adaptive): clamp the default of 4
+            lo = args.min_k if args.min_k is not None else 1
+            hi = args.max_k if args.max_k is not None else max(4, lo)
+            cp["initial_k"] = max(lo, min(4, hi))
     else:
         controller, cp = "fixed", {"k": args.K}
     try:

@@ -10,8 +10,8 @@ import sys
 
 
 def short(name):
-    name = name.replace("void sd::", "").replace("sd::", "")
-    for a, b in (("(sd::GemvArgs)", ""), ("(sd::AttnArgs)", ""), ("(sd::EmbedArgs)", "")):
+    name = name.replace("(anonymous namespace)::", "").replace("void sd::", "").replace("sd::", "")
+    for a, b in (("(GemvArgs)", ""), ("(AttnArgs)", ""), ("(EmbedArgs)", ""), ("(PersistArgs)", "")):
         name = name.replace(a, b)
     return name[:60]
 

@@ -526,10 +526,11 @@ def test_rejection_sampling_policy_in_the_pipeline():
         tok = ref.draw(torch.from_numpy(nxt), float(ref.uniforms(1)[0]))
         emitted = drafted[:a] + [tok]
         if 2 in emitted:
-            emitted = emitted[: emitted.index(2) + 1]
+            emitted = emitted[: emitted.index(2) + 1][: mt - len(gen)]
             seq, gen = seq + emitted, gen + emitted
             proposed, accepted = proposed + k, accepted + a + 1
             break
+        emitted = emitted[: mt - len(gen)]          # trimmed to the budget
         seq, gen, proposed, accepted = seq + emitted, gen + emitted, proposed + k, accepted + a + 1
     assert got["generated_tokens"] == gen
     assert (got["proposed"], got["accepted"]) == (proposed, accepted)

@@ -61,6 +61,29 @@ def test_hiplm_generate_tokens_contract_and_prefix_reuse():
     assert lm.get_kv_cache() is None
 
 
+def test_hiplm_kv_hook_on_paged_engine_equals_dense():
+    """get_kv_cache() of a paged engine gathers the rows' pages into dense [B,H,n,D] tensors: equal, bit for bit, to the
+    views a dense engine returns for the same tokens (the paged forward is bit-identical to the dense one); page-crossing
+    lengths; clear_kv_cache() hands the pages back to the pool."""
+    from src.specdec import HipLM
+
+    drf, tgt = tiny_pair()
+    ids = synthetic_prompts(2, 37, tgt.config.vocab)       # 37 + 6 positions: crosses a 32-position page
+    dense = HipLM(tgt.to("cuda"), batch=2)
+    paged = HipLM(tgt.to("cuda"), batch=2, kv_page_len=32)
+    d_ids, _ = dense.generate_tokens(ids, 6, do_sample=False)
+    p_ids, _ = paged.generate_tokens(ids, 6, do_sample=False)
+    assert torch.equal(d_ids, p_ids)
+    kd, kp = dense.get_kv_cache(), paged.get_kv_cache()
+    assert kd.seq_len == kp.seq_len and kp.get_num_layers() == tgt.config.n_layers
+    for (k0, v0), (k1, v1) in zip(kd.past_key_values, kp.past_key_values):
+        assert k1.shape == k0.shape and v1.shape == v0.shape
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    assert paged._model.pages_in_use() > 0
+    paged.clear_kv_cache()
+    assert paged._model.pages_in_use() == 0 and paged.get_kv_cache() is None
+
+
 def test_scheduler_parallel_verify_matches_autoregressive_contract():
     """schedule_verification returns base tokens/logits such that position i is the target's
     greedy prediction after prefix + d_1..d_i: on the accepted prefix identical to K
