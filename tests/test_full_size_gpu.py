@@ -33,7 +33,7 @@ def _reference_greedy(target_lm, prompts, n):
     return out
 
 
-@pytest.mark.parametrize("k,batch", [(4, 1), (4, 8), (1, 8), (8, 8), (2, 3)])
+@pytest.mark.parametrize("k,batch", [(4, 1), (4, 8), (1, 8), (8, 8), (2, 3), (2, 8)])
 def test_specdec_output_is_the_targets_greedy_continuation(full_pair, k, batch):
     from src.specdec import SpeculativePipeline
 
