@@ -172,6 +172,24 @@ def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=
     res, med, rates, wall = run(prompts[0], seg_steps)
     n = len(res["generated_tokens"])
     same = gpu_rows[0][:n] == res["generated_tokens"]
+    divergence = None
+    if not same:
+        # where the GPU's tokens leave the CPU loop's, and how close the call was for the target ON THE CPU: the oracle's logits
+        # at that position, its top-2 margin and the gap of the token the GPU emitted (a flip between near-ties is bf16
+        # arithmetic under another summation order; a flip at a clear margin is a defect) — SURVEY section 7, "hard parts"
+        ref_t = res["generated_tokens"]
+        i = next((j for j, (x, y) in enumerate(zip(gpu_rows[0], ref_t)) if x != y), min(len(gpu_rows[0]), len(ref_t)))
+        if i < min(len(gpu_rows[0]), len(ref_t)):
+            lg, _ = base.forward(torch.tensor([list(prompts[0]) + ref_t[:i]]))
+            row = lg[0, -1].double()
+            rms = row.pow(2).mean().sqrt().item()
+            top2 = row.topk(2).values
+            divergence = {"token_index": i, "gpu_token": int(gpu_rows[0][i]), "cpu_token": int(ref_t[i]),
+                          "cpu_target_argmax": int(row.argmax()),
+                          "cpu_top2_margin_over_rms": float((top2[0] - top2[1]) / rms),
+                          "gpu_token_gap_over_rms": float((row.max() - row[gpu_rows[0][i]]) / rms)}
+            log(f"cpu_baseline: tokens diverge at {i}: gpu {divergence['gpu_token']} cpu {divergence['cpu_token']}, "
+                f"cpu top-2 margin {divergence['cpu_top2_margin_over_rms']:.4f} x RMS(logits)")
     g = torch.Generator().manual_seed(1234 + 10007)
     long_prompt = torch.randint(4, tgt.config.vocab, (128,), generator=g, dtype=torch.int64).tolist()
     log(f"cpu_baseline: L0=128: 1 warm-up step + {repeats} x 1 timed step")
@@ -184,6 +202,7 @@ def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=
                   f"accumulation): 1 warm-up step, then {repeats} repeats of {seg_steps} steps each, median of the per-repeat rates "
                   f"{[round(r, 3) for r in rates]} tokens/s ({n} tokens, {wall:.1f} s in all)",
         "acceptance_rate": res["acceptance_rate"],
+        "divergence": divergence,     # null when the GPU emitted the CPU sample's tokens
         "L0_128": {"value": med_l, "unit": "tokens/s", "rates": [round(r, 3) for r in rates_l],
                    "sample": f"a 128-token synthetic prompt, 1 warm-up step + {repeats} x 1 step ({wall_l:.1f} s)"},
     }, bool(same)

@@ -70,6 +70,12 @@
 #ifndef SD_P_SPLIT3
 #define SD_P_SPLIT3 0      // wide rows swept by all three consumers (the leader joins after its last epilogue)
 #endif
+#ifndef SD_P_LEADIN_UNITS
+#define SD_P_LEADIN_UNITS 96   // the leader multiplies in single-tile ops of at least this many MFMAs per tile (down-projection)
+#endif
+#ifndef SD_P_DIAG
+#define SD_P_DIAG 0        // diagnostic build: the timeline instance times the third consumer's MFMA part in shader cycles (slots 8-11)
+#endif
 #ifndef SD_P_INFLIGHT
 #define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
 #endif
@@ -524,15 +530,19 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* ringp, unsigned 
   }
 }
 
-template <bool DIAG = false, class C>
-__device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, ConsState& st, const LeadLane& L, int ts_mfma) {
+// NP > 0: every tile of the op has exactly NP pairs (8: gate/up, lm_head; 6: Llama-3.2-1B QKV; 4: out- / down-projection,
+// double-stepped) and a whole number of chunks — the tile geometry is then a compile-time constant and the prologue of a wave's
+// MFMA part (1000 shader cycles from entry to the first LDS read in the generic form, measured; it sits on the critical path of
+// every op) shrinks to the ring position. NP = 0: any geometry (partial last tiles, other models).
+template <int NP = 0, bool DIAG = false, class C>
+__device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, ConsState& st, const LeadLane& L, int ts_mfma, unsigned useq_need) {
   // ONE copy of this routine for the three consumers (the leader's parts under a wave-uniform branch): the launch's code must
   // stay inside the 64 KiB instruction cache two CUs share — with a copy per role (and per call site of the gathers) the
   // kernel was ~150 KiB and every phase of every wave started on instructions fetched from memory
   const bool LEAD = cw == 0;
   const PersistArgs& a = *c.a;
   ChunkDiag dg{};
-  unsigned long long d_t = 0, d_loop0 = 0;
+  unsigned long long d_t = 0, d_loop0 = 0, d_first = 0, d_end = 0;
   if constexpr (DIAG) d_loop0 = __builtin_amdgcn_s_memtime();
   const int lane = c.lane, g = lane >> 4, n = lane & 15;
   const unsigned ring = a.ring_bytes;
@@ -543,16 +553,16 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
   float* part_all = reinterpret_cast<float*>(c.smem + a.lds_part);
   const unsigned op_abs0 = st.piece0 * kPiece;
   const bool multi = o.n_tiles > 1;
-  const bool dbl0 = !multi && o.my_pairs == 4 && (o.steps & 1) == 0;
+  const bool dbl0 = NP ? NP == 4 : (!multi && o.my_pairs == 4 && (o.steps & 1) == 0);
   const int units0 = dbl0 ? o.steps >> 1 : o.steps;
-  const bool lead_in = !multi && (units0 >= 96 || (SD_P_LEADQKV && o.my_pairs != 4 && o.my_pairs != 8 && units0 > kChunk));
+  const bool lead_in = !multi && (units0 >= SD_P_LEADIN_UNITS || (SD_P_LEADQKV && o.my_pairs != 4 && o.my_pairs != 8 && units0 > kChunk));
   const int share = lead_in ? 3 : 2;
   // (when it does multiply, the leader takes the short share: chunk 2, 5, ... of a tile)
   const int first_chunk = lead_in ? (cw + 2) % 3 : cw - 1;   // -1: this wave (the leader) does not multiply in this op
   if (LEAD && !lead_in) lds_st(&c.ctl->consumed[0], st.piece0 + o.pieces);   // never reads this op's weights
   for (int tile = 0; tile < o.n_tiles; ++tile) {
-    const int np = min(o.tile_pairs, o.my_pairs - tile * o.tile_pairs);
-    const bool dbl = np == 4 && (o.steps & 1) == 0;
+    const int np = NP ? NP : min(o.tile_pairs, o.my_pairs - tile * o.tile_pairs);
+    const bool dbl = NP ? NP == 4 : (np == 4 && (o.steps & 1) == 0);
     const unsigned sb = static_cast<unsigned>(np) * 128u;   // bytes of one 32-k step of the tile
     const unsigned ub = dbl ? 1024u : sb;                   // bytes of one MFMA's worth (a "unit")
     const int units = dbl ? o.steps >> 1 : o.steps;
@@ -564,13 +574,19 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
     const unsigned char* xrow = dbl ? xrow_dbl : xrow_std;
     const unsigned xstep = dbl ? 128u : 64u;
     EpiPrep prep{};
-    if (LEAD) prep = epilogue_prep(c, o, tile, np, L);
+    if (LEAD) {
+      prep = epilogue_prep(c, o, tile, np, L);
+      // The leader enters the op without waiting for the staged rows: its epilogue operands (addresses, RoPE factors, the old
+      // residual) do not depend on them, so they are computed while the gatherer still sweeps; only when it multiplies itself
+      // (long single-tile ops) does it need the rows — the other consumers waited for them before they came here.
+      if (tile == 0 && lead_in && !wait_word<1>(c, &c.ctl->u_seq, useq_need, ST_USEQ)) return false;
+    }
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int ch = first_chunk; ch >= 0 && ch < n_chunk; ch += share) {
       const unsigned off = tile_off + static_cast<unsigned>(ch * kChunk) * ub;
-      const int ns = min(kChunk, units - ch * kChunk);
+      const int ns = NP ? kChunk : min(kChunk, units - ch * kChunk);
       const unsigned need = st.piece0 + ((off + static_cast<unsigned>(ns) * ub + kPiece - 1) / kPiece);
-      if constexpr (DIAG) d_t = __builtin_amdgcn_s_memtime();
+      if constexpr (DIAG) { d_t = __builtin_amdgcn_s_memtime(); if (!d_first) d_first = d_t; }
       if (st.landed < need) {
         for (unsigned spins = 1;; ++spins) {
           st.landed = lds_ld(&c.ctl->landed);
@@ -609,12 +625,7 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
       lds_st(&c.ctl->consumed[cw], st.piece0 + nxt_off / kPiece);
     }
     if (tile == o.n_tiles - 1 && ts_mfma >= 0) stamp(c, ts_mfma);   // diagnostic: this wave's MFMA part of the op is done
-    if constexpr (DIAG) {
-      if (tile == o.n_tiles - 1 && ts_mfma >= 0 && c.lane == 0) {
-        unsigned long long* d = c.a->debug_ts + static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + ts_mfma + 3;   // slots 8..11 of the op
-        d[0] = dg.wait; d[1] = dg.reads; d[2] = dg.mfma; d[3] = (dg.chunks << 32) | ((__builtin_amdgcn_s_memtime() - d_loop0) & 0xffffffffull);
-      }
-    }
+    if constexpr (DIAG) d_end = __builtin_amdgcn_s_memtime();
     // ---- hand the partial to the leader (double-buffered by tile parity)
     if (st.tile_no >= 2 && !wait_word<1>(c, &c.ctl->lead_done, st.tile_no - 1, ST_PART)) return false;
     float* part = part_all + (st.tile_no & 1u) * (3 * 16 * kPartT);
@@ -631,9 +642,20 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
     }
     ++st.tile_no;
     lds_st(&c.ctl->done[cw], st.tile_no);
+    if constexpr (DIAG) {
+      if (tile == o.n_tiles - 1 && ts_mfma >= 0 && c.lane == 0) {   // slots 8..11 of the op, shader cycles
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = c.a->debug_ts + static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + ts_mfma + 3;
+        if (!d_first) d_first = d_end;
+        d[0] = d_first - d_loop0;                                   // prologue: entry -> first chunk
+        d[1] = dg.reads + dg.mfma + dg.wait;                        // LDS reads + MFMAs + waiting for weights
+        d[2] = (d_end - d_first) - (dg.reads + dg.mfma + dg.wait);  // everything else inside the chunk loop
+        d[3] = t3 - d_end;                                          // partial tile + done flag
+      }
+    }
     if (LEAD) {
       if (!wait_word<1>(c, &c.ctl->done[1], st.tile_no, ST_PART) || !wait_word<1>(c, &c.ctl->done[2], st.tile_no, ST_PART)) return false;
-      if (tile == o.n_tiles - 1 && ts_mfma >= 0) stamp(c, ts_mfma + 3);   // diagnostic (slot 9): the last tile's partials are in
+      if (!SD_P_DIAG && tile == o.n_tiles - 1 && ts_mfma >= 0) stamp(c, ts_mfma + 3);   // diagnostic (slot 9): the last tile's partials are in
       if (lead_in) {
         if (dbl) epilogue_finish<0, true>(c, o, prep, part, L, st);
         else epilogue_finish<0, false>(c, o, prep, part, L, st);
@@ -768,7 +790,7 @@ __device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, in
       }
     const float sq = wave_reduce_sum(s2.x + s2.y);
     const float rs = rsqrtf(sq / static_cast<float>(a.d_model) + a.norm_eps);
-    if (t == 0) { if (ts >= 0) stamp(c, ts + 8); if (!wait_rows_free(c, st)) return false; }
+    if (t == 0) { if (!SD_P_DIAG && ts >= 0) stamp(c, ts + 8); if (!wait_rows_free(c, st)) return false; }
     unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u + static_cast<unsigned>(t) * a.u_stride);
 #pragma unroll
     for (int hc = 0; hc < HC; ++hc)
@@ -933,7 +955,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
     }
     if (SD_P_THINATT) lds_st(&c.ctl->gathering, 0u);
     lds_st(&c.ctl->a_seq, unit_no);
-    stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
+    if (!SD_P_DIAG) stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
   } else {
     if (!wait_word<1>(c, &c.ctl->a_seq, unit_no, ST_ATTN)) return false;
   }
@@ -1037,7 +1059,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
   lds_st(&c.ctl->a_done[cw], unit_no);
   if (cw == 0) {
     if (!wait_word<1>(c, &c.ctl->a_done[1], unit_no, ST_ATTN) || !wait_word<1>(c, &c.ctl->a_done[2], unit_no, ST_ATTN)) return false;
-    stamp(c, ts + 11);   // diagnostic: the three partials are in
+    if (!SD_P_DIAG) stamp(c, ts + 11);   // diagnostic: the three partials are in
     const unsigned tag = edge_tag(c, layer, PE_ATTN);
     for (int it = lane; it < M * half; it += 64) {
       const int r = it / half, dj = it - r * half;
@@ -1163,11 +1185,30 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
       if (SD_P_THIN) lds_st(&c.ctl->gathering, 0u);
       lds_st(&c.ctl->u_seq, static_cast<unsigned>(i + 1));
       stamp(c, 12 * i + 1);
-    } else {
+    } else if (cw == 2) {
       if (!wait_word<1>(c, &c.ctl->u_seq, static_cast<unsigned>(i + 1), ST_USEQ)) return;
-      if (cw == 2) stamp(c, 12 * i + 4);
+      stamp(c, 12 * i + 4);
+    }   // (the leader: see consume_op)
+    {
+      const int ts = cw == 0 ? 12 * i + 6 : (cw == 2 ? 12 * i + 5 : -1);
+      // regular geometry: whole tiles of 8 / 6 / 4 pairs and whole chunks (see consume_op)
+      const bool whole = o.my_pairs > 0 && o.my_pairs % o.tile_pairs == 0;
+      const int units = (o.tile_pairs == 4) ? o.steps >> 1 : o.steps;
+      const bool reg = whole && (o.tile_pairs != 4 || (o.steps & 1) == 0) && units % kChunk == 0;
+      bool ok2;
+      if (SD_P_DIAG && C::kStamps && cw == 2) {
+        if (reg && o.tile_pairs == 8) ok2 = consume_op<8, true>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else if (reg && o.tile_pairs == 4) ok2 = consume_op<4, true>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else if (reg && o.tile_pairs == 6) ok2 = consume_op<6, true>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else ok2 = consume_op<0, true>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+      } else {
+        if (reg && o.tile_pairs == 8) ok2 = consume_op<8>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else if (reg && o.tile_pairs == 4) ok2 = consume_op<4>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else if (reg && o.tile_pairs == 6) ok2 = consume_op<6>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+        else ok2 = consume_op<0>(c, cw, o, st, L, ts, static_cast<unsigned>(i + 1));
+      }
+      if (!ok2) return;
     }
-    if (!consume_op(c, cw, o, st, L, cw == 0 ? 12 * i + 6 : (cw == 2 ? 12 * i + 5 : -1))) return;
     if (cw == 0) stamp(c, 12 * i + 2);
     if (o.kind == POP_QKV && unit >= 0) {
       if (!attention_unit<D>(c, cw, o.layer, unit / a.n_q_heads, unit % a.n_q_heads, st, 12 * i)) return;

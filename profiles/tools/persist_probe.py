@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--max-t", type=int, default=2)
     ap.add_argument("--no-timeline", action="store_true")
+    ap.add_argument("--diag", action="store_true", help="library built with -DSD_P_DIAG=1: slots 8-11 are the third consumer's cycle counts")
     a = ap.parse_args()
     sh = dict(SHAPES[a.model])
     if a.layers:
@@ -76,7 +77,10 @@ def main():
                 def d(x, y):   # mean over CUs that have both stamps
                     m = (ev[:, i, x] > 0) & (ev[:, i, y] > 0)
                     return float((ev[m, i, x] - ev[m, i, y]).mean() / 100.0) if m.any() else float("nan")
-                row.update(sweep=d(8, 0), parts=d(9, 1), fin=d(2, 9), a_stage=d(10, 2), a_comp=d(11, 10), a_merge=d(3, 11))
+                if a.diag:
+                    row.update(c_pre=ev[:, i, 8].mean(), c_body=ev[:, i, 9].mean(), c_loop=ev[:, i, 10].mean(), c_tail=ev[:, i, 11].mean())
+                else:
+                    row.update(sweep=d(8, 0), parts=d(9, 1), fin=d(2, 9), a_stage=d(10, 2), a_comp=d(11, 10), a_merge=d(3, 11))
                 tot.setdefault(kind, []).append(row)
                 if 4 <= i < 12 or i >= n_ops - 1:
                     print(f"{kind + str(i // 4):>10s} {e[:, 0].mean():9.2f} {e[:, 1].mean():9.2f} {e[:, 2].mean():9.2f} {at:8.2f} {e[:, 7].mean():9.2f} | "
@@ -84,9 +88,13 @@ def main():
             print("per op kind, mean over layers (us):")
             for k, v in tot.items():
                 print(f"  {k:7s} " + "  ".join(f"{name} {np.mean([r[name] for r in v]):6.2f}" for name in ("gather", "w3wait", "mfma", "lead_mfma", "epi", "total")) + f"   (x{len(v)})")
-                print(f"          sweep returned {np.nanmean([r['sweep'] for r in v]):5.2f} after gather start | partials in {np.nanmean([r['parts'] for r in v]):5.2f} after staged | "
-                      f"epilogue+publish {np.nanmean([r['fin'] for r in v]):5.2f} | attention: q staged {np.nanmean([r['a_stage'] for r in v]):5.2f} after op_done, "
-                      f"blocks {np.nanmean([r['a_comp'] for r in v]):5.2f}, merge+publish {np.nanmean([r['a_merge'] for r in v]):5.2f}")
+                if a.diag:
+                    print(f"          third consumer, shader cycles per op: prologue {np.mean([r['c_pre'] for r in v]):7.0f} | LDS reads + MFMAs + weight waits "
+                          f"{np.mean([r['c_body'] for r in v]):7.0f} | rest of the chunk loop {np.mean([r['c_loop'] for r in v]):7.0f} | partial + done flag {np.mean([r['c_tail'] for r in v]):7.0f}")
+                else:
+                    print(f"          sweep returned {np.nanmean([r['sweep'] for r in v]):5.2f} after gather start | partials in {np.nanmean([r['parts'] for r in v]):5.2f} after staged | "
+                          f"epilogue+publish {np.nanmean([r['fin'] for r in v]):5.2f} | attention: q staged {np.nanmean([r['a_stage'] for r in v]):5.2f} after op_done, "
+                          f"blocks {np.nanmean([r['a_comp'] for r in v]):5.2f}, merge+publish {np.nanmean([r['a_merge'] for r in v]):5.2f}")
             if cfg.n_layers > 2:
                 starts = us_(ev[:, 0:4 * cfg.n_layers:4, 0]).mean(0)
                 per = np.diff(starts)
