@@ -378,14 +378,12 @@ class SpeculativePipeline:
         for lm in (self.base_lm, self.draft_lm):
             if lm is not None:
                 lm.clear_kv_cache()
-        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "accepted_draft": 0, "device_ms": 0.0, "void_row_steps": 0}
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
         step = 0
         while any(r.active for r in rows):
             step += 1
-            # the controller sees the STRICT rate (accepted draft tokens / proposed, <= 1): the reported `accepted` counts the
-            # bonus / correction token as generate_batch does and would read (k+1)/k on a fully accepted step
             ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
-                   "acceptance_rate": stats["accepted_draft"] / max(stats["proposed"], 1)}
+                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
             k = int(self.controller.get_k(step, ctx))
             if k <= 0:
                 break
@@ -436,12 +434,14 @@ class SpeculativePipeline:
         n = len(rows)
         for lm in (self.base_lm, self.draft_lm):
             lm.clear_kv_cache()
-        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "device_ms": 0.0, "void_row_steps": 0}
+        stats = {"steps": 0, "resyncs": 0, "proposed": 0, "accepted": 0, "accepted_draft": 0, "device_ms": 0.0, "void_row_steps": 0}
         step = 0
         while any(r.active for r in rows):
             step += 1
+            # the controller sees the STRICT rate (accepted draft tokens / proposed, <= 1): the reported `accepted` counts the
+            # bonus / correction token as generate_batch does and would read (k+1)/k on a fully accepted step
             ctx = {"step": step, "generated_tokens": max(len(r.generated) for r in rows),
-                   "acceptance_rate": stats["accepted"] / max(stats["proposed"], 1)}
+                   "acceptance_rate": stats["accepted_draft"] / max(stats["proposed"], 1)}
             k = int(self.controller.get_k(step, ctx))
             if k <= 0:
                 break
