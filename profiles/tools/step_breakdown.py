@@ -10,8 +10,8 @@ import sys
 
 
 def short(n):
-    n = n.replace("void sd::", "").replace("sd::", "")
-    for a in ("(sd::GemvArgs)", "(sd::AttnArgs)", "(sd::EmbedArgs)"):
+    n = n.replace("(anonymous namespace)::", "").replace("void sd::", "").replace("sd::", "")
+    for a in ("(sd::GemvArgs)", "(sd::AttnArgs)", "(sd::EmbedArgs)", "(sd::PersistArgs)", "(PersistArgs)"):
         n = n.replace(a, "")
     return n.split("(")[0][:48]
 
