@@ -80,6 +80,13 @@
 #define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
 #endif
 
+#ifndef SD_P_UNIF
+// Wait loops whose give-up test is forced wave-uniform, one bit per site (see expired()): 1 wait_word, 2 loader, 4 chunk loop,
+// 8 granule sweeps, 16 attention sweep. All 32 combinations measured on one box (us per 1B forward; 0: 613): 5 -> 601, 7 -> 592,
+// 13 -> 587, 15 -> 592; every combination of 1 with 16 -> 718-754 (profiles/round3_persist_ab.md).
+#define SD_P_UNIF 13
+#endif
+
 namespace sd {
 namespace {
 
@@ -143,8 +150,15 @@ struct PCtxT {
 __device__ __attribute__((noinline)) bool expired_slow(const unsigned* abort_word, unsigned long long t_start) {
   return lds_ld(abort_word) != 0u || static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - t_start) > kTimeoutTicks;
 }
-template <class C>
-__device__ __forceinline__ bool expired(const C& c) { return expired_slow(&c.ctl->abort_, c.t_start); }
+// SITE: which wait loop asks (experiment switch SD_P_UNIF, one bit per site: 0 wait_word, 1 loader, 2 chunk loop, 3 sweeps, 4 attention sweep)
+template <int SITE = 0, class C>
+__device__ __forceinline__ bool expired(const C& c) {
+  // (the callee's result comes back in a VGPR: without the readfirstlane every exit of every wait loop is a divergent branch,
+  //  and every value carried around such a loop — ring positions, piece counts, tile numbers — leaves the scalar unit)
+  const bool e = expired_slow(&c.ctl->abort_, c.t_start);
+  if constexpr ((SD_P_UNIF >> SITE) & 1) return __builtin_amdgcn_readfirstlane(static_cast<int>(e)) != 0;
+  else return e;
+}
 __device__ __attribute__((noinline)) void give_up_slow(unsigned* abort_word, unsigned* status, unsigned code, int lane) {
   lds_st(abort_word, 1u);
   if (lane == 0) atomicOr(status, code);
@@ -163,7 +177,7 @@ __device__ __forceinline__ void stamp(const C& c, int slot) {
 template <int NAP, class C>
 __device__ __forceinline__ bool wait_word(const C& c, const unsigned* p, unsigned need, unsigned code) {
   for (unsigned spins = 1; lds_ld(p) < need; ++spins) {
-    if ((spins & 1023u) == 0u && expired(c)) { give_up(c, code); return false; }
+    if ((spins & 1023u) == 0u && expired<0>(c)) { give_up(c, code); return false; }
   }
   return true;
 }
@@ -233,7 +247,7 @@ __device__ __forceinline__ void loader_role(const C& c) {
         lds_st(&c.ctl->landed, pub);
       }
       __builtin_amdgcn_s_sleep(2);
-      if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_LOADER); return; }
+      if ((spins & 255u) == 0u && expired<1>(c)) { give_up(c, ST_LOADER); return; }
     }
     if (SD_P_THIN == 2) {
       for (unsigned spins = 1; lds_ld(&c.ctl->gathering); ++spins) {
@@ -243,7 +257,7 @@ __device__ __forceinline__ void loader_role(const C& c) {
           lds_st(&c.ctl->landed, pub);
         }
         __builtin_amdgcn_s_sleep(2);
-        if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_LOADER); return; }
+        if ((spins & 255u) == 0u && expired<1>(c)) { give_up(c, ST_LOADER); return; }
       }
     }
     unsigned n = 0;
@@ -592,7 +606,7 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
           st.landed = lds_ld(&c.ctl->landed);
           if constexpr (DIAG) dg.spins += 1;
           if (st.landed >= need) break;
-          if ((spins & 1023u) == 0u && expired(c)) { give_up(c, ST_LANDED); return false; }
+          if ((spins & 1023u) == 0u && expired<2>(c)) { give_up(c, ST_LANDED); return false; }
         }
       }
       if constexpr (DIAG) dg.wait += __builtin_amdgcn_s_memtime() - d_t;
@@ -726,14 +740,14 @@ __device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base
     issue(xa);
     __builtin_amdgcn_sched_barrier(0);
     if (complete(xb)) return true;
-    if ((spins & 127u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
+    if ((spins & 127u) == 0u && expired<3>(c)) { give_up(c, ST_GRANULE); return false; }
   }
 #else
   for (unsigned spins = 1;; ++spins) {
     issue(xa);
     if (complete(xa)) return true;
     __builtin_amdgcn_s_sleep(SD_P_BACKOFF);
-    if ((spins & 255u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
+    if ((spins & 255u) == 0u && expired<3>(c)) { give_up(c, ST_GRANULE); return false; }
   }
 #endif
 }
@@ -938,7 +952,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
         issue(xa);
         __builtin_amdgcn_sched_barrier(0);
         if (complete(xb)) break;
-        if ((spins & 127u) == 0u && expired(c)) { give_up(c, ST_GRANULE); return false; }
+        if ((spins & 127u) == 0u && expired<4>(c)) { give_up(c, ST_GRANULE); return false; }
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l)

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--max-t", type=int, default=2)
     ap.add_argument("--no-timeline", action="store_true")
+    ap.add_argument("--persist-only", action="store_true", help="skip the launch-path reference run")
     ap.add_argument("--diag", action="store_true", help="library built with -DSD_P_DIAG=1: slots 8-11 are the third consumer's cycle counts")
     a = ap.parse_args()
     sh = dict(SHAPES[a.model])
@@ -41,7 +42,7 @@ def main():
     cfg = W.ModelConfig(arch=W.ARCH_LLAMA, vocab=128256, max_pos=4096, rope_theta=500000.0, tie_embeddings=True, name=a.model, **sh)
     mw = W.random_init(cfg, seed=0, device="cuda")
     res = {}
-    for label, max_t in (("persistent", a.max_t), ("launches", 0)):
+    for label, max_t in (("persistent", a.max_t),) + (() if a.persist_only else (("launches", 0),)):
         os.environ["SPECDEC_PERSIST_MAX_T"] = str(max_t)
         hm = HipModel(mw, batch=1, l_max=max(512, a.ctx + 64))
         if a.ctx:
