@@ -597,11 +597,12 @@ static int carve_workspace(sd_model* m, void* workspace) {
       add(4 * c.n_layers, c.final_norm_w, (c.vocab + 1) / 2, c.d_model, POP_HEAD, c.n_layers);
       SD_HIP_CHECK(hipMemcpy(m->p_ops, ops.data(), ops.size() * sizeof(PersistOp), hipMemcpyHostToDevice));
       int cap = persist_max_tokens(c);
-      // tokens per pass the persistent launch takes (0 = off). Default 1: at Llama-3.2-1B dimensions a 1-token forward runs
-      // 662 us persistent against 700 us as 83 launches (128 cached positions, same box), but a 2-token pass 820-840 against 720:
-      // every hand-off carries two rows and the ring loses 16 KiB to the second staged row (profiles/round3_persist_ab.md)
+      // tokens per pass the persistent launch takes (0 = off), by measurement (same box, 128 cached positions, us per forward,
+      // persistent / launches; profiles/round3_persist_ab.md): Llama-3.2-1B dimensions 1 token 596 / 698, 2 tokens 677 / 718,
+      // 3 tokens 838 / 741; Llama-3.2-3B dimensions 1 token 1506 / 1495, 2 tokens 1640 / 1540. So: 2 tokens up to
+      // d_model = 2048 (the draft), off above it (the target's passes stay on launches).
       const char* env = getenv("SPECDEC_PERSIST_MAX_T");
-      const int want = env ? atoi(env) : 1;
+      const int want = env ? atoi(env) : (c.d_model <= 2048 ? 2 : 0);
       m->persist_t = cap < want ? cap : want;
     }
   }

@@ -67,9 +67,6 @@
 #ifndef SD_P_LEADQKV
 #define SD_P_LEADQKV 0     // the leader multiplies in short single-tile ops whose tiles are not 1-KiB units (QKV at 6 pairs)
 #endif
-#ifndef SD_P_SPLIT3
-#define SD_P_SPLIT3 0      // wide rows swept by all three consumers (the leader joins after its last epilogue)
-#endif
 #ifndef SD_P_LEADIN_UNITS
 #define SD_P_LEADIN_UNITS 96   // the leader multiplies in single-tile ops of at least this many MFMAs per tile (down-projection)
 #endif
@@ -108,7 +105,7 @@ struct PCtl {   // LDS control words (all written with relaxed workgroup-scope a
   unsigned a_done[3];    // attention partials written
   unsigned a_merged;     // attention units merged
   unsigned g2_seq;       // ops whose second half of the input rows the third consumer has staged (wide rows only)
-  unsigned g3_seq;       // the same for the leader's third (SD_P_SPLIT3)
+  unsigned a2_seq;       // attention units whose odd new positions the third consumer has staged (M > 1)
   unsigned gathering;    // the gatherer is sweeping: the loader keeps one slot in flight (its bursts queue in front of the sweep's loads)
 };
 
@@ -755,7 +752,8 @@ __device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base
 // input rows of a norm-fused op (QKV, GATEUP, HEAD): gather the d_model-wide rows (granules of edge `edge`, or the
 // embedding rows for layer 0), RMSNorm them (HF LlamaRMSNorm: weight * (x * rsqrt(mean(x^2) + eps)).to(bf16)), stage as bf16
 template <int HC, class C>
-__device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts) {
+__device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts, int t0, int tstep,
+                                                 int me) {
   const PersistArgs& a = *c.a;
   const int npt = a.d_model >> 1;   // dwords (pairs) per row
   const unsigned* nw = static_cast<const unsigned*>(o.norm_w);
@@ -767,7 +765,7 @@ __device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, in
       const int idx = hc * 1024 + j * 64 + c.lane;
       wv[hc][j] = nw[idx < npt ? idx : npt - 1];   // unconditional (clamped): the loads stay back to back
     }
-  for (int t = 0; t < c.T; ++t) {
+  for (int t = t0; t < c.T; t += tstep) {   // rows t0, t0 + tstep, ...: with several tokens two waves share the rows
     unsigned v[HC][16];
     if (from_embedding) {
       const int b = t / a.M, m = t - b * a.M;
@@ -804,7 +802,7 @@ __device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, in
       }
     const float sq = wave_reduce_sum(s2.x + s2.y);
     const float rs = rsqrtf(sq / static_cast<float>(a.d_model) + a.norm_eps);
-    if (t == 0) { if (!SD_P_DIAG && ts >= 0) stamp(c, ts + 8); if (!wait_rows_free(c, st)) return false; }
+    if (t == t0) { if (!SD_P_DIAG && ts >= 0) stamp(c, ts + 8); if (!wait_rows_free(c, st, me)) return false; }
     unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u + static_cast<unsigned>(t) * a.u_stride);
 #pragma unroll
     for (int hc = 0; hc < HC; ++hc)
@@ -837,12 +835,12 @@ __device__ __forceinline__ bool gather_plain_chunks(const C& c, const unsigned l
 
 // granules [lo, hi) of every token row (npt per row); wave `me` of the three consumers does the sweeping
 template <class C>
-__device__ __forceinline__ bool gather_plain_rows(const C& c, int layer, int edge, int npt, int lo, int hi, const ConsState& st, int me) {
+__device__ __forceinline__ bool gather_plain_rows(const C& c, int layer, int edge, int npt, int lo, int hi, const ConsState& st, int me, int t0, int tstep) {
   const PersistArgs& a = *c.a;
   const unsigned tag = edge_tag(c, layer, edge);
   const unsigned long long* g = edge_base(a, layer, edge);
   bool first_write = true;
-  for (int t = 0; t < c.T; ++t) {
+  for (int t = t0; t < c.T; t += tstep) {
     unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u + static_cast<unsigned>(t) * a.u_stride);
     for (int c0 = lo; c0 < hi;) {
       const int left = hi - c0;
@@ -905,15 +903,16 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
   // the scratch is rewritten (this unit's sweep and partials) only after the leader has merged the previous unit
   if (cw != 0 && st.att_no > 0 && !wait_word<1>(c, &c.ctl->a_merged, st.att_no, ST_ATTN)) return false;
 
-  if (cw == 1) {
-    if (SD_P_THINATT) lds_st(&c.ctl->gathering, 1u);
+  const bool pos_shared = M > 1;   // several new positions: even ones swept by the gatherer, odd ones by the third consumer
+  if (cw == 1 || (cw == 2 && pos_shared)) {
+    if (SD_P_THINATT && cw == 1) lds_st(&c.ctl->gathering, 1u);
     // sweep q_h, k_kvh, v_kvh of the M new positions: granule (t, pair p) holds rows (i, i + half) of head p / half.
     // 3 * half granules per position = NL loads per lane, unconditional (clamped) and all in flight (see sweep)
     constexpr int NL = (3 * (D / 2) + 63) / 64;
     const int n_pairs = (Hq + 2 * Hkv) * half;
     const unsigned tag = edge_tag(c, layer, PE_QKV);
     const unsigned long long* gq = edge_base(a, layer, PE_QKV);
-    for (int m = 0; m < M; ++m) {
+    for (int m = cw - 1; m < M; m += pos_shared ? 2 : 1) {
       const unsigned g0 = static_cast<unsigned>(b * M + m) * n_pairs;
       const unsigned long long* p[NL];
       int sel[NL], ii[NL];
@@ -967,9 +966,15 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
           }
         }
     }
-    if (SD_P_THINATT) lds_st(&c.ctl->gathering, 0u);
-    lds_st(&c.ctl->a_seq, unit_no);
-    if (!SD_P_DIAG) stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
+    if (cw == 2) {
+      lds_st(&c.ctl->a2_seq, unit_no);
+      if (!wait_word<1>(c, &c.ctl->a_seq, unit_no, ST_ATTN)) return false;
+    } else {
+      if (pos_shared && !wait_word<1>(c, &c.ctl->a2_seq, unit_no, ST_ATTN)) return false;
+      if (SD_P_THINATT) lds_st(&c.ctl->gathering, 0u);
+      lds_st(&c.ctl->a_seq, unit_no);
+      if (!SD_P_DIAG) stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
+    }
   } else {
     if (!wait_word<1>(c, &c.ctl->a_seq, unit_no, ST_ATTN)) return false;
   }
@@ -1166,32 +1171,29 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
     // the workgroups run in near lockstep: before this CU's own leader has published the previous op, no sweep can complete
     if (cw != 0 && !wait_word<1>(c, &c.ctl->lead_done, st.tile_no, ST_PART)) return;
 #endif
+    // One token: the gatherer stages the row (the third consumer sweeps the second half of wide plain rows). Several tokens:
+    // the rows go alternately to the gatherer and the third consumer, so a second token costs no second round of sweeps
+    // (measured before: every gather of a 2-token pass took 1.6-2x the 1-token time, +10 us per layer).
+    const bool rows_shared = c.T > 1;
     if (normed) {
-      if (cw == 1) {
+      if (cw == 1 || (cw == 2 && rows_shared)) {
         const int edge = (o.kind == POP_GATEUP) ? PE_X2 : PE_X;   // the head reads the rows the last down-projection left (layer index n_layers)
         const bool emb = (o.kind == POP_QKV && o.layer == 0) || (o.kind == POP_HEAD && a.n_layers == 0);
-        ok = gather_norm_rows<HC>(c, o, edge, emb, st, 12 * i);
-      }
-    } else if (SD_P_SPLIT3 && ((o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1) > kSplitSweep) {
-      const int edge = (o.kind == POP_OUT) ? PE_ATTN : PE_ACT;
-      const int npt = (o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1;
-      const int third = (npt / 3) & ~63;
-      const int lo = (cw == 1) ? 0 : (cw == 2 ? third : 2 * third), hi = (cw == 1) ? third : (cw == 2 ? 2 * third : npt);
-      ok = gather_plain_rows(c, o.layer, edge, npt, lo, hi, st, cw);
-      if (ok) {
-        if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
-        else if (cw == 0) lds_st(&c.ctl->g3_seq, static_cast<unsigned>(i + 1));
-        else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ) && wait_word<1>(c, &c.ctl->g3_seq, static_cast<unsigned>(i + 1), ST_USEQ);
+        ok = gather_norm_rows<HC>(c, o, edge, emb, st, cw == 1 ? 12 * i : -1, cw - 1, rows_shared ? 2 : 1, cw);
+        if (ok && rows_shared) {
+          if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
+          else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ);
+        }
       }
     } else if (cw != 0) {
       const int edge = (o.kind == POP_OUT) ? PE_ATTN : PE_ACT;
       const int npt = (o.kind == POP_OUT) ? (a.n_q_heads * a.head_dim) >> 1 : a.d_ff >> 1;
-      const int mid = (npt > kSplitSweep) ? ((npt >> 1) + 1023) & ~1023 : npt;
-      const int lo = (cw == 1) ? 0 : mid, hi = (cw == 1) ? mid : npt;
-      if (lo < hi) ok = gather_plain_rows(c, o.layer, edge, npt, lo, hi, st, cw);
-      if (ok && mid < npt) {
+      const int mid = rows_shared ? npt : ((npt > kSplitSweep) ? ((npt >> 1) + 1023) & ~1023 : npt);
+      const int lo = (cw == 1 || rows_shared) ? 0 : mid, hi = (cw == 1 || rows_shared) ? mid : npt;
+      if (lo < hi) ok = gather_plain_rows(c, o.layer, edge, npt, lo, hi, st, cw, rows_shared ? cw - 1 : 0, rows_shared ? 2 : 1);
+      if (ok && (mid < npt || rows_shared)) {
         if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
-        else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ);   // the third consumer's half
+        else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ);   // the third consumer's part
       }
     }
     if (!ok) return;
