@@ -5,33 +5,38 @@
 // What it replaces: the 5-launches-per-layer forward of engine.hip (itself the replacement of the reference's k-step
 // draft loop, /root/reference/src/specdec/models/hf_wrappers.py:417-539, driven from src/specdec/core/pipeline.py:2397).
 // With one launch per operator every kernel pays its own head (arguments, first weights in flight) and tail (reduce,
-// epilogue, drain) with HBM idle, and a boundary between them: 38 us per Llama-3.2-1B layer for 121.6 MB (3.2 TB/s).
+// epilogue, drain) with HBM idle, and a boundary between them: 38 us per Llama-3.2-1B layer for 121.6 MB (3.2 TB/s);
+// this launch runs the same layer in ~32 us (profiles/round3_persist_ab.md).
 // Here the weight stream never waits for a dependency:
 //
 //   * one 256-thread workgroup per CU (256 of them, all resident: each declares the CU's whole LDS), four waves with
 //     fixed roles, one per SIMD:
 //       wave 0  LOADER   walks the CU's share of every matrix in stream order (the packed tile streams of csrc/pack.hip:
 //                        workgroup c owns a contiguous byte range of each matrix) and copies it into a byte RING in LDS
-//                        with LDS-DMA (global_load_lds_dwordx4 ... nt, 1 KiB per wave-instruction, 16-piece slots, up to
-//                        3 slots in flight behind a counted vmcnt). It depends on nothing but ring space, so it runs
-//                        AHEAD of every dependency of the layer: while the consumers wait for activations, the next
-//                        ~120 KiB of weights land.
+//                        with LDS-DMA (global_load_lds_dwordx4 ... nt, 1 KiB per wave-instruction, 16-piece slots, two
+//                        slots in flight behind a counted vmcnt, one while this CU sweeps). It depends on nothing but
+//                        ring space, so it runs AHEAD of every dependency of the layer: while the consumers wait for
+//                        activations, the next ~100 KiB of weights land.
 //       waves 1-3        CONSUMERS: v_mfma_f32_16x16x32_bf16 on 1-KiB A fragments read from the ring (ds_read_b128) with the
-//                        staged activations as B; the three take the 8-step chunks of a tile round-robin and hand their
-//                        16x16 partials to the leader through LDS. Besides that,
-//       wave 1  LEADER   folds the partial tiles, runs the fused epilogue (RoPE + KV append, residual, SwiGLU, argmax)
-//                        and PUBLISHES the results to the other CUs;
-//       wave 2  GATHERER sweeps the NEXT op's input vector from the other CUs (its loads are in flight while the leader
-//                        still runs the epilogue of this op), normalises it and stages it in LDS.
+//                        staged activations as B, in chunks of 16 fragments (all LDS reads of a chunk issued before its
+//                        first MFMA); the chunks of a tile go round-robin over the waves that multiply in the op and
+//                        their 16x16 partials reach the leader through LDS. Besides that,
+//       wave 1  LEADER   (consumer 0) folds the partial tiles, runs the fused epilogue (RoPE + KV append, residual, SwiGLU,
+//                        argmax) and PUBLISHES the results to the other CUs; it multiplies only in long single-tile ops;
+//       wave 2  GATHERER (consumer 1) sweeps the NEXT op's input rows from the other CUs (its loads are in flight while the
+//                        leader still runs the epilogue of this op), normalises them and stages them in LDS;
+//       wave 3           (consumer 2) sweeps the second half of wide rows, and every other row of a multi-token pass.
 //   * activations cross CUs as 8-byte {tag, value} GRANULES (one relaxed agent-scope store each: the data is the flag,
-//     no fence, no barrier): every CU publishes the <= 64 values it owns, every CU's leader sweeps the whole vector
-//     (16 dwordx2 loads per lane per 8 KiB) until all tags match. tag = (launch << 9) | (layer, edge), so no buffer is
-//     ever re-initialised; buffers alternate with the layer parity.
-//   * attention of (row, q head) units runs on 32 of the CUs (3 waves split the cached keys, MFMA QK^T / PV as in
+//     no fence, no barrier): every CU publishes the <= 64 values it owns, every CU's gatherer sweeps the whole vector
+//     (16 dwordx2 loads per lane per 8 KiB, all in flight) until all tags match. tag = (launch << 9) | (layer, edge), so
+//     no buffer is ever re-initialised; buffers alternate with the layer parity.
+//   * attention of (row, q head) units runs on B x Hq of the CUs (3 waves split the cached keys, MFMA QK^T / PV as in
 //     attention_device.h, the new positions' K/V come from the granules), the other CUs wait for its output with their
 //     loaders still prefetching.
 //   * nothing spins unbounded: every wait checks a 50 ms deadline on the 100 MHz clock and an abort word in LDS;
-//     on expiry the workgroup sets sync[1] and leaves (the host reads it with the step record).
+//     on expiry the workgroup sets a status bit in sync[1] and leaves (the host reads it with the step record and raises).
+//   * every control value a wave derives from an LDS word is made wave-uniform explicitly (readfirstlane): one wave per SIMD
+//     issues an instruction every ~5 cycles, and exec-masked control flow around the wait loops cost 4 % of the forward.
 //
 // Numerics: the same bf16 rounding points as the launch-per-operator forward (normalised rows, q/k/v, attention rows,
 // residual stream, activations and logits are bf16; sums are fp32); the order of the fp32 sums differs (3 interleaved
@@ -1369,7 +1374,9 @@ static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
                                      static_cast<int>(kLdsBytes)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS>), dim3(kPersistCUs), dim3(256), smem, st, a);
+  // test hook (tests/test_hip_persist_gpu.py): one workgroup short, so granules are missing and every bounded wait has to expire
+  const int grid = getenv("SPECDEC_PERSIST_TEST_DROP_WG") ? kPersistCUs - 1 : kPersistCUs;
+  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS>), dim3(grid), dim3(256), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }

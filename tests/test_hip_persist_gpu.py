@@ -227,3 +227,33 @@ def test_full_depth_1b_shape_matches_launch_path(monkeypatch):
         sure = (top2[..., 0] - top2[..., 1]) > 2 * band
         assert torch.equal(ids_p[sure], ids_l[sure])
     assert pa.engine_status() == 0
+
+
+def test_a_launch_that_cannot_complete_gives_up_and_reports(monkeypatch):
+    """Every wait of the persistent launch is bounded (50 ms on the 100 MHz clock): launched ONE WORKGROUP SHORT (test hook
+    SPECDEC_PERSIST_TEST_DROP_WG: the granules of workgroup 255 and the attention unit it hosts never appear) the launch must
+    come back on its own, leave a non-zero status word for the host, and the engine must serve the next pass again once the
+    hook is gone (tags advance per launch, so the incomplete buffers are simply stale)."""
+    import time
+
+    mw = W.synthetic_llama(TOY, seed=4, device="cpu", layer_gain=0.05)
+    pa, la = _engines(mw, 1, 128, monkeypatch)
+    seq = synthetic_prompts(1, 8, TOY.vocab, seed=5)
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for hm in (pa, la):
+        hm.forward(_dev(seq[:, :-1]), zero, 0, skip_head=True)
+    pos = torch.tensor([7], dtype=torch.int32, device="cuda")
+    assert pa.engine_status() == 0
+    monkeypatch.setenv("SPECDEC_PERSIST_TEST_DROP_WG", "1")
+    t0 = time.time()
+    pa.forward(_dev(seq[:, -1:]), pos, 0)
+    torch.cuda.synchronize()
+    took = time.time() - t0
+    monkeypatch.delenv("SPECDEC_PERSIST_TEST_DROP_WG")
+    status = pa.engine_status()
+    assert status != 0, "an incomplete launch must leave its give-up code"
+    assert took < 5.0, f"the launch took {took:.2f} s to give up"
+    # the same pass again, complete this time: the launch path's token
+    got, _ = pa.forward(_dev(seq[:, -1:]), pos, 0)
+    want, _ = la.forward(_dev(seq[:, -1:]), pos, 0)
+    assert torch.equal(got.cpu(), want.cpu())
