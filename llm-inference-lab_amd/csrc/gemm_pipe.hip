@@ -445,12 +445,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_pipe_kernel(const GemvArgs 
         for (int q = 0; q < TG; ++q) {
           const int t = 16 * q + tl;
           if (t < T) {
-            const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
-            float y0 = 0.f, y1 = 0.f;
-            for (int w = 0; w < ksplit; ++w) {
-              y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
-              y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
-            }
+            float y0, y1;
+            sum_slices(part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256 + jp * 16 + tl, TG * 256, ksplit, y0, y1);
             if constexpr (W8) {
               y0 *= a.w_scale[r0];
               y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;

@@ -359,12 +359,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_skinny_kernel(const GemvArg
         for (int q = 0; q < TG; ++q) {
           const int t = 16 * q + tl;
           if (t < T) {
-            const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
-            float y0 = 0.f, y1 = 0.f;
-            for (int w = 0; w < ksplit; ++w) {
-              y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
-              y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
-            }
+            float y0, y1;
+            sum_slices(part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256 + jp * 16 + tl, TG * 256, ksplit, y0, y1);
             if constexpr (W8) {
               y0 *= a.w_scale[r0];
               y1 *= (r1 < a.N) ? a.w_scale[r1] : 0.f;
@@ -518,12 +514,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_direct_kernel(const GemvArg
       for (int q = 0; q < TG; ++q) {
         const int t = 16 * q + tl;
         if (t < T) {
-          const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
-          float y0 = 0.f, y1 = 0.f;
-          for (int w = 0; w < ksplit; ++w) {
-            y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
-            y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
-          }
+          float y0, y1;
+          sum_slices(part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256 + jp * 16 + tl, TG * 256, ksplit, y0, y1);
           if constexpr (EPI == EPI_RESID) epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q], false, 0u, &st_sq[q], &st_sum[q]);
           else epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
         }
@@ -717,12 +709,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemm_slice_kernel(const GemvArgs
       for (int q = 0; q < TG; ++q) {
         const int t = 16 * q + tl;
         if (t < T) {
-          const float* base = part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256;
-          float y0 = 0.f, y1 = 0.f;
-          for (int w = 0; w < ksplit; ++w) {
-            y0 += base[static_cast<size_t>(w) * TG * 256 + jp * 16 + tl];
-            y1 += base[static_cast<size_t>(w) * TG * 256 + (jp + 8) * 16 + tl];
-          }
+          float y0, y1;
+          sum_slices(part + static_cast<size_t>(tsl * ksplit) * TG * 256 + q * 256 + jp * 16 + tl, TG * 256, ksplit, y0, y1);
           if constexpr (EPI == EPI_RESID) epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q], true, oldv[q], &st_sq[q], &st_sum[q]);
           else epilogue<EPI>(a, p, r0, r1, t, y0, y1, best_v[q], best_i[q]);
         }

@@ -429,12 +429,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       const int etile = r * tiles_per_round + ts;
       const int p = p_lo + etile * tile_pairs + jp;
       if (etile < n_tiles && jp < tile_pairs && p < p_hi && t < T) {
-        const float* base = part + (ts * ksplit) * 256;
-        float y0 = 0.f, y1 = 0.f;
-        for (int w = 0; w < ksplit; ++w) {
-          y0 += base[w * 256 + jp * 16 + t];
-          y1 += base[w * 256 + (jp + 8) * 16 + t];
-        }
+        float y0, y1;
+        sum_slices(part + (ts * ksplit) * 256 + jp * 16 + t, 256, ksplit, y0, y1);   // (gemv_device.h)
         int r0, r1;
         pair_rows<EPI>(a, p, r0, r1);
         if constexpr (W8) {
