@@ -223,8 +223,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
       if (j >= j0 && j < j1) {
-        const int s = (j < steps) ? j : steps - 1;
-        buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + static_cast<size_t>(s) * wstride + lane_off));
+        // (32-bit element offsets from the wave-uniform tile base: a workgroup's share of a matrix is far below 2^31 elements; as
+        //  size_t products every load of the batch cost ~11 scalar instructions of 64-bit address arithmetic in the launch's preamble)
+        const unsigned s = (j < steps) ? j : steps - 1;
+        buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + (s * static_cast<unsigned>(wstride) + lane_off) * 2u));
       }
     }
   };
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       const int s = s0 + j;
       bool ok = s < steps;  // wave-uniform
       if constexpr (MASK && !W8) ok = ok && (a.packed ? (k_begin + s * 32 < K32) : (k_begin + s * 32 + g * 8 + 8 <= K));
-      if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + static_cast<size_t>(s) * wstride + lane_off));
+      if (ok) buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + (static_cast<unsigned>(s) * static_cast<unsigned>(wstride) + lane_off) * 2u));
       else buf[j] = u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const int tt = (t < T) ? t : T - 1;
-        xr[t] = *reinterpret_cast<const u32x4*>(xin + static_cast<size_t>(tt) * a.x_stride + cidx * 8);
+        xr[t] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xin) + (static_cast<unsigned>(tt) * static_cast<unsigned>(a.x_stride) + static_cast<unsigned>(cidx) * 8u) * 2u);   // (32-bit offsets: <= 64 rows of <= 16384 elements)
       }
     }
     if (a.prologue != PRO_NONE) {  // kernel-uniform
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_mfma_kernel(const GemvArgs 
       const int p = p_lo + ts * tile_pairs + jp;
       have_old = ts < tiles_per_round && ts < n_tiles && jp < tile_pairs && p < p_hi && t < T;
       const int pc = have_old ? p : p_lo, tc = have_old ? t : 0;
-      old_pre = *reinterpret_cast<const uint32_t*>(static_cast<const uint16_t*>(a.out) + static_cast<size_t>(tc) * a.out_stride + 2 * pc);
+      old_pre = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.out) + (static_cast<unsigned>(tc) * static_cast<unsigned>(a.out_stride) + 2u * static_cast<unsigned>(pc)) * 2u);
     }
   }
 

@@ -82,6 +82,12 @@
 #define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
 #endif
 
+#ifndef SD_P_NSPLIT
+#define SD_P_NSPLIT 1      // 1-token passes: the gatherer and the third consumer each sweep + normalise HALF of a norm-fused op's input row (-5 us per forward, 6 repeats)
+#endif
+#ifndef SD_P_ATTNPF
+#define SD_P_ATTNPF 1      // attention: a wave's second cached block is in flight before it computes its first (-6 us per forward at 128 cached positions; both: -7.5)
+#endif
 #ifndef SD_P_UNIF
 // Wait loops whose give-up test is forced wave-uniform, one bit per site (see expired()): 1 wait_word, 2 loader, 4 chunk loop,
 // 8 granule sweeps, 16 attention sweep. All 32 combinations measured on one box (us per 1B forward; 0: 613): 5 -> 601, 7 -> 592,
@@ -111,6 +117,8 @@ struct PCtl {   // LDS control words (all written with relaxed workgroup-scope a
   unsigned a_merged;     // attention units merged
   unsigned g2_seq;       // ops whose second half of the input rows the third consumer has staged (wide rows only)
   unsigned a2_seq;       // attention units whose odd new positions the third consumer has staged (M > 1)
+  unsigned nsum[2];      // SD_P_NSPLIT: sum of squares of each half row (float bits)
+  unsigned nseq[2];      //              op whose half-row sum is in nsum
   unsigned gathering;    // the gatherer is sweeping: the loader keeps one slot in flight (its bursts queue in front of the sweep's loads)
 };
 
@@ -703,30 +711,30 @@ __device__ __forceinline__ bool wait_rows_free(const C& c, const ConsState& st, 
 // TWO passes are kept in flight, half a round trip apart: a pass that was issued just before the last producer's granule
 // became visible comes back incomplete, and with one pass at a time the next one only starts then (a full round trip, ~1.2 us,
 // lost on most edges; measured 3.7 us from the last publish to the staged vector for an 8 KiB edge).
-template <int NC, class C>
-__device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base, unsigned first, int count, unsigned tag, unsigned (&v)[NC][16]) {
+template <int NC, int LPC = 16, class C>
+__device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base, unsigned first, int count, unsigned tag, unsigned (&v)[NC][LPC]) {
   const PersistArgs& a = *c.a;
-  const unsigned long long* p[NC][16];
+  const unsigned long long* p[NC][LPC];
 #pragma unroll
   for (int k = 0; k < NC; ++k)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < LPC; ++j) {
       const int idx = k * 1024 + j * 64 + c.lane;
       p[k][j] = base + granule_slot(a, first + static_cast<unsigned>(idx < count ? idx : count - 1));
     }
-  unsigned long long xa[NC][16], xb[NC][16];
-  auto issue = [&](unsigned long long (&x)[NC][16]) {
+  unsigned long long xa[NC][LPC], xb[NC][LPC];
+  auto issue = [&](unsigned long long (&x)[NC][LPC]) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) x[k][j] = __hip_atomic_load(p[k][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < LPC; ++j) x[k][j] = __hip_atomic_load(p[k][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto complete = [&](const unsigned long long (&x)[NC][16]) {
+  auto complete = [&](const unsigned long long (&x)[NC][LPC]) {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < LPC; ++j) {
         v[k][j] = static_cast<unsigned>(x[k][j]);
         ok &= static_cast<unsigned>(x[k][j] >> 32) == tag;
       }
@@ -820,6 +828,60 @@ __device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, in
   return true;
 }
 
+// SD_P_NSPLIT, 1-token passes: half of the row per wave (me = 1: first half, 2: second half). The post-sweep arithmetic of a
+// whole row (statistic, two roundings per element, 16 LDS stores per lane) is ~1.1 us on one wave and sits on the critical
+// path of three edges per layer; the two halves exchange their sums of squares through LDS (first half + second half in both
+// waves, so both normalise with the same factor).
+template <int HC, class C>
+__device__ __forceinline__ bool gather_norm_half(const C& c, const OpView& o, int edge, bool from_embedding, const ConsState& st, int ts, int me, unsigned seq) {
+  const PersistArgs& a = *c.a;
+  constexpr int LP = HC == 1 ? 8 : 16;   // loads per lane for half a row (d_model <= 2048: <= 512 granules)
+  const int npt = a.d_model >> 1, half = npt >> 1, c0 = (me == 2) ? half : 0;
+  const unsigned* nw = static_cast<const unsigned*>(o.norm_w) + c0;
+  unsigned wv[LP];
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    const int idx = j * 64 + c.lane;
+    wv[j] = nw[idx < half ? idx : half - 1];
+  }
+  unsigned v[1][LP];
+  if (from_embedding) {
+    int tok = a.tokens[0];
+    tok = tok < 0 ? 0 : (tok >= a.vocab ? a.vocab - 1 : tok);   // validate_and_clamp_tokens (token_validation.py:15-78)
+    const unsigned* row = reinterpret_cast<const unsigned*>(static_cast<const uint16_t*>(a.tok_emb) + static_cast<size_t>(tok) * a.d_model) + c0;
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int idx = j * 64 + c.lane;
+      v[0][j] = row[idx < half ? idx : half - 1];
+    }
+  } else {
+    if (!sweep<1, LP>(c, edge_base(a, o.layer, edge), static_cast<unsigned>(c0), half, edge_tag(c, o.layer, edge), v)) return false;
+  }
+  f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    if (j * 64 + c.lane >= half) v[0][j] = 0u;   // clamped duplicates do not count in the statistic
+    const f32x2_t f = bf16x2_unpack(v[0][j]);
+    s2 += f * f;
+  }
+  const float mine = wave_reduce_sum(s2.x + s2.y);
+  lds_st(&c.ctl->nsum[me - 1], __float_as_uint(mine));
+  lds_st(&c.ctl->nseq[me - 1], seq);
+  if (!wait_word<1>(c, &c.ctl->nseq[2 - me], seq, ST_USEQ)) return false;
+  const float other = __uint_as_float(lds_ld(&c.ctl->nsum[2 - me]));
+  const float sq = (me == 1) ? mine + other : other + mine;
+  const float rs = rsqrtf(sq / static_cast<float>(a.d_model) + a.norm_eps);
+  if (!SD_P_DIAG && ts >= 0) stamp(c, ts + 8);
+  if (!wait_rows_free(c, st, me)) return false;
+  unsigned* dst = reinterpret_cast<unsigned*>(c.smem + a.lds_u) + c0;
+#pragma unroll
+  for (int j = 0; j < LP; ++j) {
+    const int idx = j * 64 + c.lane;
+    if (idx < half) dst[idx] = rmsnorm_pair(v[0][j], rs, wv[j]);
+  }
+  return true;
+}
+
 // input rows taken as they are (attention rows for the out-projection, activations for the down-projection)
 template <int NC, class C>
 __device__ __forceinline__ bool gather_plain_chunks(const C& c, const unsigned long long* g, unsigned first, int count, unsigned tag, unsigned* dst,
@@ -905,6 +967,9 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
   };
   u32x4 kf0[2][NKS], vf0[NDT];
   if (cw < nb_old) load_block(cw, kf0, vf0);   // in flight while q is on its way
+  u32x4 kf1[2][NKS], vf1[NDT];
+  const bool second = SD_P_ATTNPF && cw + 3 < nb_old;
+  if (second) load_block(cw + 3, kf1, vf1);
   // the scratch is rewritten (this unit's sweep and partials) only after the leader has merged the previous unit
   if (cw != 0 && st.att_no > 0 && !wait_word<1>(c, &c.ctl->a_merged, st.att_no, ST_ATTN)) return false;
 
@@ -1048,7 +1113,8 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
   };
 
   if (cw < nb_old) block(kf0, vf0, pos0 - cw * 32, false);
-  for (int blk = cw + 3; blk < nb_old; blk += 3) {
+  if (second) block(kf1, vf1, pos0 - (cw + 3) * 32, false);
+  for (int blk = cw + (SD_P_ATTNPF ? 6 : 3); blk < nb_old; blk += 3) {
     u32x4 kf[2][NKS], vf[NDT];
     load_block(blk, kf, vf);
     block(kf, vf, pos0 - blk * 32, false);
@@ -1181,11 +1247,13 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
     // (measured before: every gather of a 2-token pass took 1.6-2x the 1-token time, +10 us per layer).
     const bool rows_shared = c.T > 1;
     if (normed) {
-      if (cw == 1 || (cw == 2 && rows_shared)) {
+      const bool halves = SD_P_NSPLIT && !rows_shared && (a.d_model & 255) == 0;   // (half a row in whole 64-granule sweeps)
+      if (cw == 1 || (cw == 2 && (rows_shared || halves))) {
         const int edge = (o.kind == POP_GATEUP) ? PE_X2 : PE_X;   // the head reads the rows the last down-projection left (layer index n_layers)
         const bool emb = (o.kind == POP_QKV && o.layer == 0) || (o.kind == POP_HEAD && a.n_layers == 0);
-        ok = gather_norm_rows<HC>(c, o, edge, emb, st, cw == 1 ? 12 * i : -1, cw - 1, rows_shared ? 2 : 1, cw);
-        if (ok && rows_shared) {
+        if (halves) ok = gather_norm_half<HC>(c, o, edge, emb, st, cw == 1 ? 12 * i : -1, cw, static_cast<unsigned>(i + 1));
+        else ok = gather_norm_rows<HC>(c, o, edge, emb, st, cw == 1 ? 12 * i : -1, cw - 1, rows_shared ? 2 : 1, cw);
+        if (ok && (rows_shared || halves)) {
           if (cw == 2) lds_st(&c.ctl->g2_seq, static_cast<unsigned>(i + 1));
           else ok = wait_word<1>(c, &c.ctl->g2_seq, static_cast<unsigned>(i + 1), ST_USEQ);
         }
