@@ -1,1 +1,4 @@
-for rep in 1 2 3 4 5 6; do for v in cur ns pf nspf; do SPECDEC_PERSIST_MAX_T=2 SPECDEC_HIP_LIB=_ab_$v/libspecdec_hip.so timeout -k 10 120 python profiles/tools/persist_probe.py --model 1b --iters 100 --no-timeline --persist-only 2>&1 | grep "persistent" | awk -v v=$v '{printf "%s %s | ", v, $4}'; done; echo; done
+for rep in 1 2 3; do for v in old new; do
+  if [ $v = old ]; then export SPECDEC_HIP_LIB=_ab_oldattn/libspecdec_hip.so; else unset SPECDEC_HIP_LIB; fi
+  python bench.py --steps 40 --warmup 5 --cpu-baseline-steps 0 --no-probe 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],4), end=' | ')"
+done; echo; done
