@@ -32,6 +32,11 @@ struct SpecState {
   int32_t* ctl;         // [B][4] accepted so far, proposed so far, history length (<= 4), k of the step just done
   double* ctl_hist;     // [B][4] the last four reported acceptance rates, oldest first
   int32_t* k_active;    // [1]    max k_row over the active rows
+  // one-sequence loops with a persistent draft: which form of draft forward 0 the NEXT step needs. {2, 1}: the 2-token
+  // pass over (prev, last) — prev's K/V are not in the draft cache yet (all k proposals were accepted: d_k was never an
+  // input, or the host has just set the row); {1, 2}: prev's K/V are there, the 1-token pass over `last` is enough.
+  // Both passes are in the captured step; each returns at entry unless its word is > 1 (SD_SKIP_IF_INACTIVE).
+  int32_t* fwd0_w;      // [2]    null: always the 2-token pass
 };
 
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);

@@ -1018,7 +1018,20 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     // per-row adaptive K: forward i >= 1 only matters while some row proposes more than i tokens
     s->draft->skip_k = (s->st.adaptive && i >= 1) ? s->st.k_active : nullptr;
     s->draft->skip_i = i;
-    const int rc_f = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+    int rc_f;
+    if (i == 0 && s->st.fwd0_w) {
+      // both forms of forward 0, the device picks (SpecState::fwd0_w, written by accept_kernel): the 2-token pass, then the
+      // 1-token pass over `last` alone, whose id lands where the 2-token pass leaves its second one
+      s->draft->skip_k = s->st.fwd0_w;
+      s->draft->skip_i = 1;
+      rc_f = model_forward(s->draft, toks, 2, s->st.cur_len, -1, 0, B, 2, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+      if (!rc_f) {
+        s->draft->skip_k = s->st.fwd0_w + 1;
+        rc_f = model_forward(s->draft, toks + 1, 2, s->st.cur_len, 0, 0, B, 1, s->st.draft_ids + 1, 2, nullptr, SD_BF16, 0, st_d);
+      }
+    } else {
+      rc_f = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+    }
     s->draft->skip_k = nullptr;
     if (rc_f) return rc_f;
     if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
@@ -1068,7 +1081,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   s->mode = emit_mode;
   s->rec = 7 + 3 * K;
   const size_t n_state = static_cast<size_t>(B) * (1 + 1 + 2 + 1 + 2 + K + (K + 1) + (K + 1) + 1 + 1 + (K + 1) + 1);
-  const size_t n_adapt = static_cast<size_t>(B) * (1 + 4 + 8) + 2 + 2;   // k_row, ctl, ctl_hist (doubles), k_active (+ alignment)
+  const size_t n_adapt = static_cast<size_t>(B) * (1 + 4 + 8) + 2 + 2 + 2;   // k_row, ctl, ctl_hist (doubles), k_active (+ alignment), fwd0_w
   const size_t n_total = n_state + 4 + n_adapt;
   hipError_t e = hipMalloc(&s->dev_block, n_total * sizeof(int32_t));
   if (e != hipSuccess) {
@@ -1099,6 +1112,14 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   st.k_row = p; p += B;
   st.k_active = p; p += 1;
   st.adaptive = 0;
+  // device-selected form of draft forward 0: one sequence, a draft whose 1- and 2-token passes are persistent launches (a pass
+  // that is not needed then costs one launch that returns at entry, not 80)
+  st.fwd0_w = nullptr;
+  if (draft && B == 1 && draft->persist_t >= 2 && !draft->block_table && !getenv("SPECDEC_NO_FWD0_SELECT")) {
+    st.fwd0_w = p; p += 2;
+    const int32_t init[2] = {2, 1};
+    (void)hipMemcpy(st.fwd0_w, init, sizeof(init), hipMemcpyHostToDevice);
+  }
   if (hipHostMalloc(reinterpret_cast<void**>(&s->host_record), sizeof(int32_t) * 2 * B * s->rec, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_done[1], hipEventDisableTiming) != hipSuccess ||
@@ -1146,6 +1167,11 @@ extern "C" int sd_specdec_set_row(sd_specdec* s, int b, int seq_len, int prev_to
   SD_HIP_CHECK(hipMemcpyAsync(s->st.active + b, h + 1, 4, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.tok2 + 2 * b, h + 2, 8, hipMemcpyHostToDevice, st));
   SD_HIP_CHECK(hipMemcpyAsync(s->st.verify_tok + static_cast<size_t>(b) * (s->K + 1), h + 3, 4, hipMemcpyHostToDevice, st));
+  if (s->st.fwd0_w) {   // whatever the caller did to the caches: the next step recomputes prev's K/V
+    h[4] = 2;
+    h[5] = 1;
+    SD_HIP_CHECK(hipMemcpyAsync(s->st.fwd0_w, h + 4, 8, hipMemcpyHostToDevice, st));
+  }
   return 0;
 }
 

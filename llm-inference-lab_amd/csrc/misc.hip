@@ -321,6 +321,15 @@ __global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, in
   if (lane == 0) {
     s.accept_len[b] = a;
     s.n_new[b] = n_new;
+    if (s.fwd0_w && b == 0) {
+      // Next step's draft forward 0 (engine.hip enqueue_step). New `prev` sits at old cur_len + n_new - 1. Bonus mode: that is
+      // d_a (a >= 1; an input of draft forward a, which ran iff a < k) or the old `last` (a == 0; forward 0's input): its K/V
+      // are in the draft cache unless a == k. Draft-emit mode: prev is d_{a-1} or the old `last`: always there.
+      const int k_eff = s.adaptive ? s.k_row[b] : K;   // (before this step's controller update)
+      const bool two = !s.active[b] || (mode == 0 && a >= k_eff);
+      s.fwd0_w[0] = two ? 2 : 1;
+      s.fwd0_w[1] = two ? 1 : 2;
+    }
     if (s.adaptive) adaptive_update(s, b, a);
     if (s.active[b]) {
       const int old_last = s.tok2[b * 2 + 1];

@@ -1321,7 +1321,10 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
   }
 }
 
-template <int D, int HC, bool STAMPS>
+// SEL: the same code under a second name, for launches that carry a skip word (a pass of the captured step that may return at
+// entry: the two forms of draft forward 0, adaptive-K forwards) — so that profiles keep the launches that always run (the
+// kernel the bench's roofline line names) apart from those that sometimes return after a few hundred cycles.
+template <int D, int HC, bool STAMPS, bool SEL>
 __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
@@ -1434,23 +1437,24 @@ size_t persist_workspace_bytes(const sd_model_config& c) {
   return n;
 }
 
-template <int D, int HC, bool STAMPS>
+template <int D, int HC, bool STAMPS, bool SEL>
 static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(kLdsBytes)));
     attr_set = true;
   }
   // test hook (tests/test_hip_persist_gpu.py): one workgroup short, so granules are missing and every bounded wait has to expire
   const int grid = getenv("SPECDEC_PERSIST_TEST_DROP_WG") ? kPersistCUs - 1 : kPersistCUs;
-  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS, SEL>), dim3(grid), dim3(256), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 template <int D, int HC>
 static int launch_one(const PersistArgs& a, size_t smem, hipStream_t st) {
-  return a.debug_ts ? launch_inst<D, HC, true>(a, smem, st) : launch_inst<D, HC, false>(a, smem, st);
+  if (a.debug_ts) return launch_inst<D, HC, true, false>(a, smem, st);
+  return a.skip_k ? launch_inst<D, HC, false, true>(a, smem, st) : launch_inst<D, HC, false, false>(a, smem, st);
 }
 
 int launch_persist_forward(PersistArgs a, hipStream_t st) {

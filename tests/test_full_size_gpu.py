@@ -100,3 +100,26 @@ def test_fp8_storage_at_full_size_multi_token_passes():
     for b, w in enumerate(want):
         g = got[b]["generated_tokens"]
         assert len(g) >= 32 and g == w[: len(g)], b
+
+
+def test_device_selected_first_draft_forward_changes_nothing(full_pair, monkeypatch):
+    """One sequence with a persistent draft: the captured step holds draft forward 0 twice — the 2-token pass over (prev, last)
+    and the 1-token pass over `last` — and the device runs the one the previous step's accept length calls for
+    (engine.hip enqueue_step, misc.hip accept_kernel: prev's K/V are missing from the draft cache only after a fully accepted
+    step). The proposals must not depend on it: same tokens, same step count, same proposed / accepted counters as with the
+    selection switched off (always the 2-token pass), over a run that contains fully and partly accepted steps."""
+    from src.specdec import SpeculativePipeline
+
+    draft_lm, target_lm = full_pair
+    prompts = synthetic_prompts(1, 32, target_lm.vocab_size, seed=11).tolist()
+    k, runs = 4, {}
+    for select in (True, False):
+        if not select:
+            monkeypatch.setenv("SPECDEC_NO_FWD0_SELECT", "1")
+        pipe = SpeculativePipeline(base_lm=target_lm, draft_lm=draft_lm, controller="fixed", controller_params={"k": k}, seed=1234)
+        r = pipe.generate_batch(prompts, max_tokens=96, do_sample=False)[0]
+        runs[select] = (r["generated_tokens"], r["batch_metrics"]["total_steps"], r["proposed"], r["accepted"])
+    monkeypatch.delenv("SPECDEC_NO_FWD0_SELECT")
+    assert runs[True] == runs[False]
+    _, steps, proposed, accepted = runs[True]
+    assert steps < accepted < steps * (k + 1), "the run must mix fully and partly accepted steps"
