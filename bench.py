@@ -301,12 +301,12 @@ def roofline_leg(sess, B, K, wd, self_draft):
     if dm is not None and persist_t >= B and B == 1:
         # the whole 1-token draft forward (embedding, layers, lm_head, argmax partials) is one kernel; timed at a context of
         # prompt + 32 positions; its algorithmic bytes = every matmul weight of the draft once
-        # draft forwards 1..K-1 of a step. (Forward 0 is in the captured step twice under the kernel's second name <..., true>:
+        # draft forwards 1..K-1 of a step. (Forward 0 is in the captured step twice under the kernel's second name <..., true, false>:
         # a 2-token pass and a 1-token pass, of which the device runs one and the other returns at entry; not counted here.)
         n_fw = (K - 1) + (1 if 2 * B <= persist_t and os.environ.get("SPECDEC_NO_FWD0_SELECT") else 0)
         u, nb, _ = dm.probe_forward(M=1, iters=40, pos0=PROMPT_LEN + 32, stream=st)
         c = dm.cfg
-        rows.append({"kernel": f"persist_forward_kernel<{c.head_dim}, {1 if c.d_model <= 2048 else 2}, false, false> (draft forward, 1 token: {c.n_layers} layers + "
+        rows.append({"kernel": f"persist_forward_kernel<{c.head_dim}, {1 if c.d_model <= 2048 else 2}, false, false, false> (draft forward, 1 token: {c.n_layers} layers + "
                                "lm_head as ONE launch)", "who": "draft", "which": -1, "T": 1, "launches_per_step": n_fw, "avg_launch_us": u,
                      "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9, "us_per_step": n_fw * u})
     top = max(rows, key=lambda r: r["us_per_step"])

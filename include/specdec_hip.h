@@ -309,7 +309,8 @@ int sd_model_engine_status(sd_model* m, uint32_t* status_out, void* stream);
 /* Rows [row0, row0+n) of one of the workspace buffers the last pass left behind (bf16, asynchronous copy on `stream`):
  * which = 0 residual stream [d_model] (= sd_model_hidden_rows), 1 q after RoPE [Hq*D], 2 attention rows [Hq*D],
  * 3 MLP activation [d_ff]; all of the LAST layer. For stage-by-stage checks of the persistent launch against the
- * launch-per-operator forward. */
+ * launch-per-operator forward. (The draft model of an sd_specdec loop runs the persistent launch WITHOUT these stores unless
+ * SPECDEC_PERSIST_TAPS is set when the loop is created: its rows are then not updated by the loop's passes.) */
 int sd_model_debug_rows(sd_model* m, int which, int row0, int n, void* out, void* stream);
 
 /* Measurement hook: `iters` whole forwards of one row of M tokens (token id 0, positions pos0..pos0+M-1 of cache row 0,

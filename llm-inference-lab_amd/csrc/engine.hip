@@ -58,6 +58,7 @@ struct sd_model {
   const float* scale(int index) const { return scales.empty() ? nullptr : scales[index]; }
   // persistent forward (csrc/persist.hip): passes of <= persist_t tokens run as ONE launch
   int persist_t = 0;                       // 0 = not available for this model / device
+  bool persist_taps = true;                // stage rows written by persistent passes (sd_specdec_create turns them off for its draft)
   sd::PersistOp* p_ops = nullptr;          // device: 4 per layer + lm_head, stream order
   unsigned long long* p_gran = nullptr;    // granule buffers, two parities
   unsigned p_gran_parity = 0;
@@ -129,6 +130,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     pa.sync = m->p_sync;
     pa.skip_k = m->skip_k;
     pa.skip_i = m->skip_i;
+    pa.taps = (m->persist_taps || skip_head) ? 1 : 0;   // (a pass without the head is run FOR its hidden rows)
     pa.debug_ts = m->p_debug;
     if (int rc = launch_persist_forward(pa, st)) return rc;
     if (skip_head) return 0;
@@ -1076,6 +1078,8 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   SD_REQUIRE(s, "specdec_create: out of memory");
   s->draft = draft;
   s->target = target;
+  // nobody reads the hidden rows of a loop's draft: its persistent passes skip the stage taps (csrc/persist.hip, TAPS)
+  if (draft && !getenv("SPECDEC_PERSIST_TAPS")) draft->persist_taps = false;
   s->B = B;
   s->K = K;
   s->mode = emit_mode;

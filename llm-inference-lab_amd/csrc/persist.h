@@ -67,6 +67,7 @@ struct PersistArgs {
   unsigned ring_bytes;        // multiple of 1 KiB
   unsigned u_stride;          // bytes between token rows of the staged input
   unsigned resid_ppw;         // pairs per workgroup of the d_model-wide matrices
+  int taps;                       // 1: also write the stage rows x / q / attn / act (tests, callers that read hidden rows); 0: the draft of a loop
   unsigned long long* debug_ts;   // optional [256][4 * n_ops + n_ops] 100 MHz stamps
 };
 

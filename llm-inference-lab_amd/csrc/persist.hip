@@ -144,9 +144,14 @@ __device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsi
 
 // STAMPS: the diagnostic instance of the kernel (sd_model_probe_forward's timeline). In the product instance the stamps do not
 // exist: as a run-time check of debug_ts at ~40 sites they cost 24 us per 1B forward (same-box A/B).
-template <bool STAMPS>
+// TAPS: the instance that also leaves the last layer's stage rows in global memory (x after every residual add, q after RoPE,
+// attention rows, MLP activations: sd_model_debug_rows, and the hidden rows a caller reads after a pass that skips the head).
+// The draft of a speculative loop runs the instance without them: nobody reads a draft's hidden rows, and the stores with their
+// 64-bit address arithmetic cost 5 us per 1B forward on the leader wave (six same-box repeats: 594.2 -> 589.2).
+template <bool STAMPS, bool TAPS>
 struct PCtxT {
   static constexpr bool kStamps = STAMPS;
+  static constexpr bool kTaps = TAPS;
   const PersistArgs* a;
   unsigned char* smem;
   PCtl* ctl;
@@ -394,7 +399,7 @@ __device__ __forceinline__ EpiPrep epilogue_prep(const C& c, const OpView& o, in
     e.gran = granule_ptr(a, o.layer, PE_QKV, static_cast<unsigned>(L.t) * o.n_pairs + p);
     e.tag = edge_tag(c, o.layer, PE_QKV);
     if (h < a.n_q_heads) {
-      e.d0 = static_cast<uint16_t*>(a.q) + static_cast<size_t>(L.t) * a.n_q_heads * Dh + h * Dh + i;
+      if (C::kTaps) e.d0 = static_cast<uint16_t*>(a.q) + static_cast<size_t>(L.t) * a.n_q_heads * Dh + h * Dh + i;
       e.d1 = half;
     } else if (L.pos >= 0 && L.pos < a.l_max) {
       // in-place KV append, as epilogue<EPI_QKV_ROPE> (gemv_device.h): K rows [l_max][D], V transposed [D][l_max]
@@ -465,7 +470,7 @@ __device__ __forceinline__ void epilogue_finish(const C& c, const OpView& o, con
       const unsigned nv = static_cast<unsigned>(float_to_bf16_bits(n0)) | (static_cast<unsigned>(float_to_bf16_bits(n1)) << 16);
       store_granule(e.gran, e.tag, nv);
       *e.res = nv;
-      *e.xtap = nv;
+      if (C::kTaps) *e.xtap = nv;
     }
   } else if (o.kind == POP_GATEUP) {
     unsigned u = 0;
@@ -474,7 +479,7 @@ __device__ __forceinline__ void epilogue_finish(const C& c, const OpView& o, con
     if (e.valid && (L.jp & 1) == 0) {
       const unsigned v = u | (partner << 16);
       store_granule(e.gran, e.tag, v);
-      *e.acttap = v;
+      if (C::kTaps) *e.acttap = v;
     }
   } else {   // POP_HEAD: logits are the bf16-rounded products (epilogue<EPI_ARGMAX>)
     if (e.valid) {
@@ -1169,7 +1174,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
       const unsigned val = static_cast<unsigned>(float_to_bf16_bits(v0)) | (static_cast<unsigned>(float_to_bf16_bits(v1)) << 16);
       const int t = b * M + r;
       store_granule(granule_ptr(a, layer, PE_ATTN, static_cast<unsigned>(t) * (Hq * half) + h * half + dj), tag, val);
-      reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.attn) + static_cast<size_t>(t) * Hq * D + h * D)[dj] = val;
+      if (C::kTaps) reinterpret_cast<unsigned*>(static_cast<uint16_t*>(a.attn) + static_cast<size_t>(t) * Hq * D + h * D)[dj] = val;
     }
     lds_st(&c.ctl->a_merged, unit_no);
   }
@@ -1324,7 +1329,7 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
 // SEL: the same code under a second name, for launches that carry a skip word (a pass of the captured step that may return at
 // entry: the two forms of draft forward 0, adaptive-K forwards) — so that profiles keep the launches that always run (the
 // kernel the bench's roofline line names) apart from those that sometimes return after a few hundred cycles.
-template <int D, int HC, bool STAMPS, bool SEL>
+template <int D, int HC, bool STAMPS, bool SEL, bool TAPS>
 __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SD_SKIP_IF_INACTIVE(a.skip_k, a.skip_i);
@@ -1335,7 +1340,7 @@ __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs 
   for (int i = tid; i < 4 * D; i += 256) reinterpret_cast<unsigned*>(smem + a.lds_attn + 2 * a.M * D * 2)[i] = 0u;
   const unsigned launch = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  PCtxT<STAMPS> c;
+  PCtxT<STAMPS, TAPS> c;
   c.a = &a;
   c.smem = smem;
   c.ctl = reinterpret_cast<PCtl*>(smem);
@@ -1437,24 +1442,25 @@ size_t persist_workspace_bytes(const sd_model_config& c) {
   return n;
 }
 
-template <int D, int HC, bool STAMPS, bool SEL>
+template <int D, int HC, bool STAMPS, bool SEL, bool TAPS>
 static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(kLdsBytes)));
     attr_set = true;
   }
   // test hook (tests/test_hip_persist_gpu.py): one workgroup short, so granules are missing and every bounded wait has to expire
   const int grid = getenv("SPECDEC_PERSIST_TEST_DROP_WG") ? kPersistCUs - 1 : kPersistCUs;
-  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS, SEL>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), dim3(grid), dim3(256), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
 }
 template <int D, int HC>
 static int launch_one(const PersistArgs& a, size_t smem, hipStream_t st) {
-  if (a.debug_ts) return launch_inst<D, HC, true, false>(a, smem, st);
-  return a.skip_k ? launch_inst<D, HC, false, true>(a, smem, st) : launch_inst<D, HC, false, false>(a, smem, st);
+  if (a.debug_ts) return launch_inst<D, HC, true, false, true>(a, smem, st);
+  if (a.taps) return a.skip_k ? launch_inst<D, HC, false, true, true>(a, smem, st) : launch_inst<D, HC, false, false, true>(a, smem, st);
+  return a.skip_k ? launch_inst<D, HC, false, true, false>(a, smem, st) : launch_inst<D, HC, false, false, false>(a, smem, st);
 }
 
 int launch_persist_forward(PersistArgs a, hipStream_t st) {
