@@ -13,7 +13,7 @@ def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void sd::", "").replace("sd::", "")
     for a in ("(sd::GemvArgs)", "(sd::AttnArgs)", "(sd::EmbedArgs)", "(sd::PersistArgs)", "(PersistArgs)"):
         n = n.replace(a, "")
-    return n.split("(")[0][:48]
+    return n.split("(")[0][:64]
 
 
 def main():
