@@ -603,8 +603,12 @@ static int carve_workspace(sd_model* m, void* workspace) {
       // persistent / launches; profiles/round3_persist_ab.md): Llama-3.2-1B dimensions 1 token 596 / 698, 2 tokens 677 / 718,
       // 3 tokens 838 / 741; Llama-3.2-3B dimensions 1 token 1506 / 1495, 2 tokens 1640 / 1540. So: 2 tokens up to
       // d_model = 2048 (the draft), off above it (the target's passes stay on launches).
+      // And by context: one CU (three waves) walks a head's whole cache, where the launch path splits long rows over up to 32
+      // workgroups — 1B dimensions, 1 token, us per forward persistent / launches at 128 ... 4096 cached positions:
+      // 588 / 675, 605 / 694, 651 / 721, 723 / 764, 888 / 767, 1186 / 777. So: only for caches bound with room for <= 1536
+      // positions (sessions size the cache to prompt + budget; a captured step cannot change its kernels as a row grows).
       const char* env = getenv("SPECDEC_PERSIST_MAX_T");
-      const int want = env ? atoi(env) : (c.d_model <= 2048 ? 2 : 0);
+      const int want = env ? atoi(env) : ((c.d_model <= 2048 && m->Lmax <= 1536) ? 2 : 0);
       m->persist_t = cap < want ? cap : want;
     }
   }

@@ -257,3 +257,19 @@ def test_a_launch_that_cannot_complete_gives_up_and_reports(monkeypatch):
     got, _ = pa.forward(_dev(seq[:, -1:]), pos, 0)
     want, _ = la.forward(_dev(seq[:, -1:]), pos, 0)
     assert torch.equal(got.cpu(), want.cpu())
+
+
+def test_default_follows_model_width_and_cache_length(monkeypatch):
+    """sd_model_bind's default (engine.hip carve_workspace, by measurement): two tokens per persistent pass for d_model <= 2048 bound to
+    a cache of <= 1536 positions; off for longer caches (one CU walks a head's whole cache: at 2048 positions the launch path's
+    split-KV attention wins) and for wider models; SPECDEC_PERSIST_MAX_T overrides both."""
+    from specdec_hip.engine import HipModel
+
+    monkeypatch.delenv("SPECDEC_PERSIST_MAX_T", raising=False)
+    mw = W.synthetic_llama(TOY, seed=4, device="cuda", layer_gain=0.05)
+    assert HipModel(mw, batch=1, l_max=1536).persist_tokens == 2
+    assert HipModel(mw, batch=1, l_max=1600).persist_tokens == 0
+    wide = W.random_init(_shape_3b(1), seed=0, device="cuda")
+    assert HipModel(wide, batch=1, l_max=256).persist_tokens == 0
+    monkeypatch.setenv("SPECDEC_PERSIST_MAX_T", "1")
+    assert HipModel(mw, batch=1, l_max=4096).persist_tokens == 1
