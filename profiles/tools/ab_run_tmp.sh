@@ -1,1 +1,4 @@
-for ctx in 128 256 512 1024 2048 4096; do timeout -k 10 200 python profiles/tools/persist_probe.py --model 1b --iters 40 --no-timeline --ctx $ctx 2>&1 | grep "persistent \|launches " | awk -v c=$ctx '{printf "ctx %s %s %s | ", c, $1, $4}'; echo; done
+for rep in 1 2 3; do for v in 8 4 6 10 12; do
+  if [ $v = 8 ]; then unset SPECDEC_HIP_LIB; else export SPECDEC_HIP_LIB=_ab_kpre$v/libspecdec_hip.so; fi
+  python bench.py --steps 40 --warmup 5 --cpu-baseline-steps 0 --no-probe 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('kpre$v', round(d['ms_per_step'],4), end=' | ')"
+done; echo; done
