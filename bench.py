@@ -133,7 +133,7 @@ def cpu_threads():
     return min(visible, 16), f"min(affinity mask {visible}, 16-CPU share of a 1-GPU box)"
 
 
-def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=4, repeats=3):
+def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=4, repeats=3, gpu_counters=None):
     """Oracle (CPU restatement of the reference loop) on the host cores, bounded sample (SURVEY section 8d protocol:
     one warm-up, >= 3 timed repeats, median; CPU model and thread count stated).
       L0 = 32 (the GPU run's prompt 0): ONE run of 1 + repeats * seg_steps steps; step 1 is the warm-up, every following
@@ -172,6 +172,17 @@ def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=
     res, med, rates, wall = run(prompts[0], seg_steps)
     n = len(res["generated_tokens"])
     same = gpu_rows[0][:n] == res["generated_tokens"]
+    # ... and the draft's side of the same steps: proposed / accepted after the CPU sample's last step against the GPU row's
+    # counters after as many of ITS steps (a persistent draft that proposed other tokens would leave the output — the target's
+    # greedy continuation either way — alone and only move these)
+    counters = None
+    if gpu_counters is not None and len(gpu_counters) >= res["steps"] >= 1:
+        gp, ga, gn, _ = gpu_counters[res["steps"] - 1]
+        counters = {"steps": res["steps"], "cpu": {"proposed": res["proposed"], "accepted": res["accepted"], "tokens": n},
+                    "gpu": {"proposed": gp, "accepted": ga, "tokens": gn}}
+        counters["equal"] = counters["cpu"] == counters["gpu"]
+        same = same and counters["equal"]
+        log(f"cpu_baseline: counters after {res['steps']} steps: cpu {counters['cpu']} gpu {counters['gpu']}")
     divergence = None
     if not same:
         # where the GPU's tokens leave the CPU loop's, and how close the call was for the target ON THE CPU: the oracle's logits
@@ -202,6 +213,7 @@ def cpu_baseline(drf, tgt, prompts, k, gpu_rows, weight_dtype="bf16", seg_steps=
                   f"accumulation): 1 warm-up step, then {repeats} repeats of {seg_steps} steps each, median of the per-repeat rates "
                   f"{[round(r, 3) for r in rates]} tokens/s ({n} tokens, {wall:.1f} s in all)",
         "acceptance_rate": res["acceptance_rate"],
+        "same_steps_counters": counters,   # proposed / accepted / tokens of the CPU sample's steps against the GPU's first as many steps
         "divergence": divergence,     # null when the GPU emitted the CPU sample's tokens
         "L0_128": {"value": med_l, "unit": "tokens/s", "rates": [round(r, 3) for r in rates_l],
                    "sample": f"a 128-token synthetic prompt, 1 warm-up step + {repeats} x 1 step ({wall_l:.1f} s)"},
@@ -303,17 +315,29 @@ def roofline_leg(sess, B, K, wd, self_draft):
         # prompt + 32 positions; its algorithmic bytes = every matmul weight of the draft once
         # draft forwards 1..K-1 of a step. (Forward 0 is in the captured step twice under the kernel's second name <..., true, false>:
         # a 2-token pass and a 1-token pass, of which the device runs one and the other returns at entry; not counted here.)
-        n_fw = (K - 1) + (1 if 2 * B <= persist_t and os.environ.get("SPECDEC_NO_FWD0_SELECT") else 0)
         u, nb, _ = dm.probe_forward(M=1, iters=40, pos0=PROMPT_LEN + 32, stream=st)
+        # Forward 0 of a step ALSO runs the kernel (under its second name, <..., true, false>: the captured step holds a 2-token
+        # and a 1-token form, the device runs one, the other returns at entry): a 2-token pass after a fully accepted step or a
+        # repaired row, a 1-token pass otherwise — weighted by what this run observed.
+        n_steps = max(sess.stats.get("steps", 0), 1)
+        f_full = min(1.0, sess.stats.get("full_accepts", 0) / n_steps)
+        fwd0 = None
+        if 2 * B <= persist_t:
+            u2, _, _ = dm.probe_forward(M=2, iters=40, pos0=PROMPT_LEN + 32, stream=st)
+            select = not os.environ.get("SPECDEC_NO_FWD0_SELECT")
+            fwd0 = {"two_token_us": u2, "one_token_us": u, "fully_accepted_fraction": f_full if select else 1.0,
+                    "us_per_step": (f_full * u2 + (1.0 - f_full) * u) if select else u2}
         c = dm.cfg
+        us_step = (K - 1) * u + (fwd0["us_per_step"] if fwd0 else 0.0)
         rows.append({"kernel": f"persist_forward_kernel<{c.head_dim}, {1 if c.d_model <= 2048 else 2}, false, false, false> (draft forward, 1 token: {c.n_layers} layers + "
-                               "lm_head as ONE launch)", "who": "draft", "which": -1, "T": 1, "launches_per_step": n_fw, "avg_launch_us": u,
-                     "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9, "us_per_step": n_fw * u})
+                               "lm_head as ONE launch)", "who": "draft", "which": -1, "T": 1, "launches_per_step": (K - 1) + (1 if fwd0 else 0), "avg_launch_us": u,
+                     "bytes_per_launch": nb, "GBps": nb / (u * 1e-6) / 1e9, "us_per_step": us_step, "forward0": fwd0})
     top = max(rows, key=lambda r: r["us_per_step"])
     ach = top["GBps"]
     roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
             "frac": ach * 1e9 / HBM_PEAK_BPS, "traffic": None, "bytes_per_launch": top["bytes_per_launch"],
             "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"], "us_per_step": top["us_per_step"],
+            "forward0": top.get("forward0"),
             "selection": "the weight-streaming kernel with the largest (launches per step x average launch time), all timed in this run"}
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE x2 on
     # gfx950; profiles/summarize.py): counters cannot be read from inside this process, so the figure comes from the
@@ -383,6 +407,9 @@ def main():
     rehearsal = os.environ.get("SPECDEC_BENCH_BACKEND", "nccl") == "gloo"
     if rehearsal:
         local = 0
+        # the persistent draft forward needs all 256 CUs to itself (one workgroup per CU, spinning on the others' hand-offs):
+        # ranks that share a GPU run the launch path (include/specdec_hip.h, sd_model_engine_status_clear)
+        os.environ["SPECDEC_NO_PERSIST"] = "1"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     stats_device = torch.device("cpu") if rehearsal else device
@@ -524,7 +551,7 @@ def main():
     # ---- CPU baseline (rank 0, N = 1 only) ---------------------------------------------------
     if world == 1 and args.cpu_baseline_steps > 0:
         gpu_rows = [list(r.generated) for r in sess.rows]
-        cb, same = cpu_baseline(drf, tgt, prompts, K, gpu_rows, wd, seg_steps=args.cpu_baseline_steps)
+        cb, same = cpu_baseline(drf, tgt, prompts, K, gpu_rows, wd, seg_steps=args.cpu_baseline_steps, gpu_counters=list(sess.rows[0].counters))
         out["cpu_baseline"] = cb
         out["parity_with_cpu_sample"] = same
         out["speedup_vs_cpu_baseline"] = value / cb["value"] if cb["value"] > 0 else None

@@ -307,6 +307,35 @@ int sd_model_persist_tokens(const sd_model* m);
  * also carries the word of its models in every step record (sd_specdec_record). */
 int sd_model_engine_status(sd_model* m, uint32_t* status_out, void* stream);
 
+/* The same word as a pinned host location (NULL before the model is bound): a workgroup that gives up also stores its
+ * reason there, so whoever has just synchronised with a pass to read its ids / logits can check the pass's health with a
+ * plain load, no copy, no further synchronisation. 0 = every persistent launch since the bind / the last clear completed. */
+const uint32_t* sd_model_status_word(const sd_model* m);
+
+/* Recovery after a non-zero health word: synchronises `stream`, clears the device word and the host word and moves the launch
+ * counter past the failed launch (so that granules it left behind never match again). The passes since the failure are
+ * invalid and must be repeated — typically after sd_model_set_persist_tokens(m, 0), i.e. on the launch path.
+ * PRECONDITION of the persistent launch, for direct C callers: it needs all 256 CUs to itself while it runs (one workgroup
+ * per CU, each declaring the CU's whole LDS, spinning on the others' hand-offs). A second process on the same GPU, or a
+ * second stream of this process running another LDS-heavy kernel at the same time, can split the CUs between the two;
+ * the launch then gives up after its 50 ms bound (it never hangs) and reports here. Share a GPU only with
+ * SPECDEC_NO_PERSIST=1 or sd_model_set_persist_tokens(m, 0). */
+int sd_model_engine_status_clear(sd_model* m, void* stream);
+
+/* Tokens per pass the persistent launch takes from now on: min(max_tokens, what the model / cache allows); 0 = launch path
+ * only. Host-side state: steps already captured (sd_specdec_step) keep the kernels they were captured with — call
+ * sd_specdec_invalidate on the loops that use the model. */
+int sd_model_set_persist_tokens(sd_model* m, int max_tokens);
+
+/* The caller's bound on the CURRENT length (cached positions) of the rows the coming passes touch; max_len <= 0 or beyond
+ * the cache: the cache size (the default after a bind). The persistent launch walks a head's whole cache on one CU and is
+ * the faster path up to 1536 positions only, so a session bound for a long context starts on it and moves to the launch
+ * path when its rows pass that length (host-side state, as above: re-capture after crossing). */
+int sd_model_set_length_hint(sd_model* m, int max_len);
+
+/* 1 when a pass of T tokens of one row would run as the persistent launch right now, else 0. */
+int sd_model_persist_active(const sd_model* m, int T);
+
 /* Rows [row0, row0+n) of one of the workspace buffers the last pass left behind (bf16, asynchronous copy on `stream`):
  * which = 0 residual stream [d_model] (= sd_model_hidden_rows), 1 q after RoPE [Hq*D], 2 attention rows [Hq*D],
  * 3 MLP activation [d_ff]; all of the LAST layer. For stage-by-stage checks of the persistent launch against the
@@ -418,6 +447,11 @@ int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_draft, int 
  * the record of the older one — slot (index & 1) of sd_specdec_record. */
 long sd_specdec_launches(const sd_specdec* s);
 int sd_specdec_wait(sd_specdec* s, long launch_index);
+
+/* Drop the captured step (its kernels were chosen at capture time: after sd_model_set_persist_tokens /
+ * sd_model_set_length_hint changed a model's path, or a model was re-bound). The next sd_specdec_step runs eagerly, the
+ * one after it captures again. The caller has drained the loop's streams. */
+int sd_specdec_invalidate(sd_specdec* s);
 
 /* Block until everything enqueued on `stream` is done (hipStreamSynchronize). */
 int sd_specdec_sync(sd_specdec* s, void* stream);

@@ -60,9 +60,8 @@ static void launch_attention_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
 
 template <int D>
 static void launch_attention_d(const AttnArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if (waves <= 4) launch_attention_one<D, 4>(a, grid, st);
-  else if (waves <= 8) launch_attention_one<D, 8>(a, grid, st);
-  else launch_attention_one<D, 16>(a, grid, st);
+  (void)waves;   // always 4 (8- and 16-wave instances were measured and dropped, see launch_attention)
+  launch_attention_one<D, 4>(a, grid, st);
   // (also tried: the first block's K/V loads hoisted above the row-position load (addresses are clamped, so they
   // are always safe): 4.79 -> 4.92 us (D = 64) and 5.9 -> 6.9 us (D = 128) per launch — waves whose first block
   // does not exist then wait for cold lines they do not need;
@@ -87,17 +86,16 @@ int launch_attention(const AttnArgs& a_in, hipStream_t st) {
   const int R = G * a.M;
   const int tiles = (R + kAttnRows - 1) / kAttnRows;
   const int D = a.head_dim;
-  // 4 waves per workgroup. 8 and 16 (SPECDEC_ATTN_WAVES, kept for experiments) were measured and lose at every
-  // context length: the LDS merge grows with the wave count and a 16-wave workgroup holds a CU's LDS alone
-  // (3B + 1B, K=4: 8 K context 6.8 ms/step with 4 waves, 9.3 with 16; short contexts equal within noise).
-  int waves = 4;
-  if (const char* e = getenv("SPECDEC_ATTN_WAVES")) waves = atoi(e);
+  // 4 waves per workgroup. 8 and 16 were measured and lose at every context length: the LDS merge grows with the wave
+  // count and a 16-wave workgroup holds a CU's LDS alone (3B + 1B, K=4: 8 K context 6.8 ms/step with 4 waves, 9.3 with
+  // 16; short contexts equal within noise).
+  const int waves = 4;
   // split-KV: as many workgroups per tile as the cache could keep busy (one per 256 keys of l_max),
   // within the partial-tile workspace and ~one wave of workgroups over the chip; the kernel uses
   // fewer while the row is short. Fixed per launch site, so a captured step stays valid as rows grow.
   const int base = a.n_kv_heads * a.B * tiles;
   int ns = 1;
-  if (a.split_ws && a.split_cnt && !getenv("SPECDEC_NO_ATTN_SPLIT")) {
+  if (a.split_ws && a.split_cnt && !getenv(debug_env::kNoAttnSplit)) {
     ns = a.l_max / (kAttnBlock * kAttnSplitBlocks);
     if (ns > kAttnMaxSplit) ns = kAttnMaxSplit;
     if (ns > a.split_slots / base) ns = a.split_slots / base;

@@ -64,7 +64,25 @@ struct sd_model {
   unsigned p_gran_parity = 0;
   unsigned* p_sync = nullptr;              // [0] launch counter, [1] status
   unsigned long long* p_debug = nullptr;   // optional timeline (sd_model_probe_persist)
+  unsigned* host_status = nullptr;         // pinned host word: a persistent launch that gives up stores its reason here as well
+  int persist_cap = 0;                     // tokens per persistent pass this model / device / cache can take (0: none)
+  int len_hint = 0;                        // caller's bound on the rows' current lengths (sd_model_set_length_hint; default Lmax)
+  int ctx_limit = 0;                       // longest rows the persistent launch serves (kPersistMaxCtx; lifted by SPECDEC_PERSIST_MAX_T)
+  ~sd_model() {
+    if (host_status) (void)hipHostFree(host_status);
+  }
 };
+
+namespace sd {
+// One CU (three waves) walks a head's whole cache in the persistent launch, where the launch path splits long rows over up to 32
+// workgroups — 1B dimensions, 1 token, us per forward persistent / launches at 128 ... 4096 cached positions: 588 / 675,
+// 605 / 694, 651 / 721, 723 / 764, 888 / 767, 1186 / 777 (profiles/round3_persist_ab.md): the persistent launch serves rows of
+// up to this many positions.
+constexpr int kPersistMaxCtx = 1536;
+static bool persist_pass_ok(const sd_model* m, int T, int Bc, int Mc) {
+  return m->persist_t > 0 && T <= m->persist_t && Mc <= 8 && !m->block_table && Bc * m->cfg.n_heads <= kPersistCUs && m->len_hint <= m->ctx_limit;
+}
+}  // namespace sd
 
 namespace sd {
 
@@ -97,7 +115,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   const int pro = llama ? PRO_RMSNORM : PRO_LAYERNORM;
 
   // ---- the whole pass as ONE persistent launch (csrc/persist.hip): small passes of a dense-KV Llama model
-  if (m->persist_t > 0 && T <= m->persist_t && Mc <= 8 && !m->block_table && Bc * Hq <= kPersistCUs) {
+  if (persist_pass_ok(m, T, Bc, Mc)) {
     PersistArgs pa{};
     pa.ops = m->p_ops;
     pa.n_ops = 4 * c.n_layers + (skip_head ? 0 : 1);
@@ -128,6 +146,7 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
     pa.gran = m->p_gran;
     pa.gran_parity = m->p_gran_parity;
     pa.sync = m->p_sync;
+    pa.host_status = m->host_status;
     pa.skip_k = m->skip_k;
     pa.skip_i = m->skip_i;
     pa.taps = (m->persist_taps || skip_head) ? 1 : 0;   // (a pass without the head is run FOR its hidden rows)
@@ -435,7 +454,7 @@ extern "C" int sd_model_create(const sd_model_config* cfg, sd_model** out) {
     for (int T = kSkinnyMaxT; T >= 16 && !cover_t; T >>= 1)
       if (covers(T)) cover_t = T;
     const bool ok = cover_t != 0;
-    const char* env = getenv("SPECDEC_MAX_PASS_TOKENS");  // testing knob: 9 forces the small-T kernel everywhere
+    const char* env = getenv(debug_env::kMaxPassTokens);  // testing knob: 9 forces the small-T kernel everywhere
     int want = env ? atoi(env) : cover_t;
     if (want > cover_t) want = cover_t;
     int kmax = c.d_model > HqD ? c.d_model : HqD;
@@ -568,6 +587,10 @@ static int carve_workspace(sd_model* m, void* workspace) {
     m->p_gran = reinterpret_cast<unsigned long long*>(pp);
     m->p_gran_parity = static_cast<unsigned>((pbytes - 256 - align_up(static_cast<size_t>(4 * c.n_layers + 1) * sizeof(PersistOp), 256)) / 16);
     m->persist_t = 0;
+    m->persist_cap = 0;
+    m->len_hint = m->Lmax;
+    if (!m->host_status) SD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->host_status), 64, hipHostMallocDefault));
+    *m->host_status = 0u;
     int dev = 0;
     hipDeviceProp_t prop{};
     SD_HIP_CHECK(hipGetDevice(&dev));
@@ -598,20 +621,58 @@ static int carve_workspace(sd_model* m, void* workspace) {
       }
       add(4 * c.n_layers, c.final_norm_w, (c.vocab + 1) / 2, c.d_model, POP_HEAD, c.n_layers);
       SD_HIP_CHECK(hipMemcpy(m->p_ops, ops.data(), ops.size() * sizeof(PersistOp), hipMemcpyHostToDevice));
-      int cap = persist_max_tokens(c);
+      // (a cache whose rows are not whole 8-key vectors cannot be walked by the launch's attention: launch path)
+      m->persist_cap = persist_cache_ok(m->Lmax) ? persist_max_tokens(c) : 0;
       // tokens per pass the persistent launch takes (0 = off), by measurement (same box, 128 cached positions, us per forward,
       // persistent / launches; profiles/round3_persist_ab.md): Llama-3.2-1B dimensions 1 token 596 / 698, 2 tokens 677 / 718,
       // 3 tokens 838 / 741; Llama-3.2-3B dimensions 1 token 1506 / 1495, 2 tokens 1640 / 1540. So: 2 tokens up to
       // d_model = 2048 (the draft), off above it (the target's passes stay on launches).
-      // And by context: one CU (three waves) walks a head's whole cache, where the launch path splits long rows over up to 32
-      // workgroups — 1B dimensions, 1 token, us per forward persistent / launches at 128 ... 4096 cached positions:
-      // 588 / 675, 605 / 694, 651 / 721, 723 / 764, 888 / 767, 1186 / 777. So: only for caches bound with room for <= 1536
-      // positions (sessions size the cache to prompt + budget; a captured step cannot change its kernels as a row grows).
-      const char* env = getenv("SPECDEC_PERSIST_MAX_T");
-      const int want = env ? atoi(env) : ((c.d_model <= 2048 && m->Lmax <= 1536) ? 2 : 0);
-      m->persist_t = cap < want ? cap : want;
+      // And by context (kPersistMaxCtx): by the rows' CURRENT lengths as the caller bounds them (sd_model_set_length_hint; the
+      // default bound is the cache size: sessions that size the cache to prompt + budget need not say anything).
+      const char* env = getenv(debug_env::kPersistMaxT);
+      const int want = env ? atoi(env) : (c.d_model <= 2048 ? 2 : 0);
+      m->persist_t = m->persist_cap < want ? m->persist_cap : want;
+      m->ctx_limit = env ? m->Lmax : kPersistMaxCtx;   // (the measurement override also lifts the context bound)
     }
   }
+  return 0;
+}
+
+extern "C" int sd_model_set_persist_tokens(sd_model* m, int max_tokens) {
+  clear_error();
+  SD_REQUIRE(m && m->x, "set_persist_tokens: NULL argument / model not bound");
+  SD_REQUIRE(max_tokens >= 0, "set_persist_tokens: max_tokens=%d", max_tokens);
+  m->persist_t = max_tokens < m->persist_cap ? max_tokens : m->persist_cap;
+  return 0;
+}
+
+extern "C" int sd_model_set_length_hint(sd_model* m, int max_len) {
+  clear_error();
+  SD_REQUIRE(m && m->x, "set_length_hint: NULL argument / model not bound");
+  m->len_hint = (max_len <= 0 || max_len > m->Lmax) ? m->Lmax : max_len;
+  return 0;
+}
+
+extern "C" int sd_model_persist_active(const sd_model* m, int T) {
+  // 1 when a pass of T tokens of one row would run as the persistent launch right now (tokens, length hint, paging)
+  return (m && T >= 1 && sd::persist_pass_ok(m, T, 1, T)) ? 1 : 0;
+}
+
+extern "C" const uint32_t* sd_model_status_word(const sd_model* m) { return m ? m->host_status : nullptr; }
+
+extern "C" int sd_model_engine_status_clear(sd_model* m, void* stream) {
+  clear_error();
+  SD_REQUIRE(m, "engine_status_clear: NULL argument");
+  if (!m->p_sync) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SD_HIP_CHECK(hipStreamSynchronize(st));   // every workgroup of a failed launch has left
+  unsigned w[2] = {0u, 0u};
+  SD_HIP_CHECK(hipMemcpy(w, m->p_sync, 8, hipMemcpyDeviceToHost));
+  // past the failed launch's tags (it did not advance the counter): granules it left behind can never match again
+  w[0] = (w[0] + 2u) & 0x7fffffu;
+  w[1] = 0u;
+  SD_HIP_CHECK(hipMemcpy(m->p_sync, w, 8, hipMemcpyHostToDevice));
+  if (m->host_status) *m->host_status = 0u;
   return 0;
 }
 
@@ -649,16 +710,16 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
   SD_HIP_CHECK(hipEventCreate(&e0));
   SD_HIP_CHECK(hipEventCreate(&e1));
   unsigned long long* dbg = nullptr;
-  const bool timeline = getenv("SPECDEC_GEMV_TIMELINE") != nullptr;
+  const bool timeline = getenv(debug_env::kGemvTimeline) != nullptr;
   if (timeline) {
     SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), 256 * 16 * sizeof(unsigned long long)));
     SD_HIP_CHECK(hipMemset(dbg, 0, 256 * 16 * sizeof(unsigned long long)));
   }
   // SPECDEC_PROBE_HOT=n: cycle over n layers only (n=1: the same matrix every launch, i.e. cache-resident weights)
-  const int hot = getenv("SPECDEC_PROBE_HOT") ? atoi(getenv("SPECDEC_PROBE_HOT")) : 0;
+  const int hot = getenv(debug_env::kProbeHot) ? atoi(getenv(debug_env::kProbeHot)) : 0;
   // > 9 tokens: as in the forward, the norm-fused launches read the row statistics the previous launch left, and the
   // residual launches leave them (SPECDEC_PROBE_NO_XSTAT=1: every launch computes its own, as for the first layer)
-  const bool use_xstat = T > kGemvMaxT && T <= 64 && !getenv("SPECDEC_PROBE_NO_XSTAT");
+  const bool use_xstat = T > kGemvMaxT && T <= 64 && !getenv(debug_env::kProbeNoXstat);
   auto launch = [&](int l) -> int {
     if (hot > 0) l %= hot;
     const sd_layer_weights& w = m->layers[l % c.n_layers];
@@ -875,6 +936,8 @@ struct sd_specdec {
   int32_t* head_rows = nullptr;    // [B] device: row of the target's residual stream each head reads
   size_t head_stride = 0;          // bytes between consecutive heads when they sit at a constant stride (one launch), else 0
   // EAGLE-lite (sd_specdec_set_eagle): extrapolated hidden rows instead of a draft model; caller-owned workspace
+  bool draft_taps = false;         // the draft's persistent passes also store their stage rows (debug)
+  bool want_fwd0_select = false;   // device-selected form of draft forward 0 (storage carved at create; eligibility per capture)
   int eagle = 0;
   float eagle_alpha = 0.7f;
   uint16_t* eagle_H = nullptr;     // [B*K][d]
@@ -1017,6 +1080,15 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     SD_HIP_CHECK(hipStreamWaitEvent(st_d, s->ev_fork, 0));
   }
   // draft: forward 0 over (prev, last) at positions cur_len-1, cur_len; then one token each
+  struct TapsGuard {   // the draft's stage taps are this loop's choice, for the duration of its forwards only
+    sd_model* m; bool saved;
+    TapsGuard(sd_model* m_, bool v) : m(m_), saved(m_ ? m_->persist_taps : false) { if (m) m->persist_taps = v; }
+    ~TapsGuard() { if (m) m->persist_taps = saved; }
+  } taps_guard(s->draft, s->draft_taps);
+  // both forms of forward 0 with the device picking one: only while the draft's 1- and 2-token passes are persistent launches
+  // (a pass that is not needed then costs one launch that returns at entry, not 80) — decided per capture, the model may have
+  // been re-bound or its persistent passes switched off since the loop was created
+  const bool fwd0_select = s->draft && s->st.fwd0_w && B == 1 && persist_pass_ok(s->draft, 2, 1, 2);
   for (int i = 0; s->draft && i < K; ++i) {
     const int M = (i == 0) ? 2 : 1;
     const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
@@ -1025,7 +1097,7 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
     s->draft->skip_k = (s->st.adaptive && i >= 1) ? s->st.k_active : nullptr;
     s->draft->skip_i = i;
     int rc_f;
-    if (i == 0 && s->st.fwd0_w) {
+    if (i == 0 && fwd0_select) {
       // both forms of forward 0, the device picks (SpecState::fwd0_w, written by accept_kernel): the 2-token pass, then the
       // 1-token pass over `last` alone, whose id lands where the 2-token pass leaves its second one
       s->draft->skip_k = s->st.fwd0_w;
@@ -1082,8 +1154,10 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   SD_REQUIRE(s, "specdec_create: out of memory");
   s->draft = draft;
   s->target = target;
-  // nobody reads the hidden rows of a loop's draft: its persistent passes skip the stage taps (csrc/persist.hip, TAPS)
-  if (draft && !getenv("SPECDEC_PERSIST_TAPS")) draft->persist_taps = false;
+  // nobody reads the hidden rows of a loop's draft: its persistent passes skip the stage taps (csrc/persist.hip, TAPS). The
+  // choice belongs to the LOOP (enqueue_step sets it around the draft's forwards): the same model object used elsewhere — as a
+  // standalone model, or as another loop's target — keeps its taps.
+  s->draft_taps = getenv(debug_env::kPersistTaps) != nullptr;
   s->B = B;
   s->K = K;
   s->mode = emit_mode;
@@ -1123,7 +1197,7 @@ extern "C" int sd_specdec_create(sd_model* draft, sd_model* target, int B, int K
   // device-selected form of draft forward 0: one sequence, a draft whose 1- and 2-token passes are persistent launches (a pass
   // that is not needed then costs one launch that returns at entry, not 80)
   st.fwd0_w = nullptr;
-  if (draft && B == 1 && draft->persist_t >= 2 && !draft->block_table && !getenv("SPECDEC_NO_FWD0_SELECT")) {
+  if (draft && B == 1 && draft->persist_cap >= 2 && !getenv(debug_env::kNoFwd0Select)) {
     st.fwd0_w = p; p += 2;
     const int32_t init[2] = {2, 1};
     (void)hipMemcpy(st.fwd0_w, init, sizeof(init), hipMemcpyHostToDevice);
@@ -1342,7 +1416,7 @@ extern "C" int sd_specdec_set_medusa(sd_specdec* s, int n_heads, const void* con
     }
   }
   s->head_stride = 0;
-  if (n_heads >= 2 && !getenv("SPECDEC_MEDUSA_PER_HEAD")) {
+  if (n_heads >= 2 && !getenv(debug_env::kMedusaPerHead)) {
     const char* h0 = static_cast<const char*>(packed_heads[0]);
     const char* h1 = static_cast<const char*>(packed_heads[1]);
     bool even = h1 > h0;
@@ -1392,6 +1466,19 @@ extern "C" int sd_specdec_step(sd_specdec* s, void* stream_target, void* stream_
   SD_HIP_CHECK(hipGraphLaunch(s->exec, st_t));
   SD_HIP_CHECK(hipEventRecord(s->ev_done[s->launches & 1], st_t));   // completion of THIS step (sd_specdec_wait)
   s->launches++;
+  return 0;
+}
+
+extern "C" int sd_specdec_invalidate(sd_specdec* s) {
+  clear_error();
+  SD_REQUIRE(s, "specdec_invalidate: NULL");
+  if (s->exec) {
+    (void)hipGraphExecDestroy(s->exec);
+    (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+  }
+  s->steps = 0;   // the next step runs eagerly (kernels of the other path may still need their one-time attribute setup)
   return 0;
 }
 

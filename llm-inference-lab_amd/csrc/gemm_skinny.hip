@@ -823,15 +823,15 @@ static int launch_skinny_epi(const GemvArgs& a, const SkinnyGeom& sg, int grid, 
 // consumer would then fold stale partial sums with no error). The knobs are read once.
 enum SkinnyBody { BODY_DIRECT, BODY_SLICE, BODY_PIPE, BODY_CHUNKED };
 static SkinnyBody choose_skinny_body(const GemvArgs& a, const GemvGeom& q, int epi) {
-  static const bool no_direct = getenv("SPECDEC_NO_DIRECT") != nullptr;
-  static const bool no_pipe = getenv("SPECDEC_NO_PIPE") != nullptr;
-  static const int slice_min_t = getenv("SPECDEC_SLICE_MIN_T") ? atoi(getenv("SPECDEC_SLICE_MIN_T")) : 17;
+  static const bool no_direct = getenv(debug_env::kNoDirect) != nullptr;
+  static const bool no_pipe = getenv(debug_env::kNoPipe) != nullptr;
+  constexpr int slice_min_t = 17;
   const int TG = (a.T + 15) / 16;
   const bool plain_resid = !a.w8 && a.prologue == PRO_NONE && epi == EPI_RESID;
   // un-normalised, single-round shapes (out / down projections): operands straight to registers (measured on the 3B shapes:
   // ahead of the staged kernel up to 16 tokens, behind it from 24 — its B loads touch 16 rows x 64 bytes per instruction)
   if (TG == 1 && plain_resid && q.n_tiles <= kGemvWaves / q.ksplit && !no_direct) return BODY_DIRECT;
-  // ... and from 17 tokens the wave-private staging (SPECDEC_SLICE_MIN_T moves the hand-over for experiments)
+  // ... and from 17 tokens the wave-private staging
   if (a.T >= slice_min_t && a.T <= 48 && plain_resid && slice_covers(a, q, TG)) return BODY_SLICE;
   // the statically scheduled chunk pipeline (gemm_pipe.hip) for everything else up to 64 tokens
   if (!no_pipe && a.T <= 64 && gemm_pipe_covers(a.T, a.n_pairs, a.K, a.w8 != 0)) return BODY_PIPE;

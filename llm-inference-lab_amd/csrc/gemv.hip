@@ -518,11 +518,9 @@ static int launch_epi_w(const GemvArgs& a, bool mask, int grid, size_t smem, hip
 
 template <int EPI>
 static int launch_epi(const GemvArgs& a, bool mask, int grid, size_t smem, hipStream_t st) {
-  static const int deep_steps = getenv("SPECDEC_GEMV_DEEP_STEPS") ? atoi(getenv("SPECDEC_GEMV_DEEP_STEPS")) : kDeepSteps;
   // (3+ token launches, i.e. the verify forward: 16 — threshold 24 / 16 / 12 / 6 -> 4.62 / 4.60 / 4.62 / 4.63 ms per step)
-  static const int deep_steps_t = getenv("SPECDEC_GEMV_DEEP_STEPS_T3") ? atoi(getenv("SPECDEC_GEMV_DEEP_STEPS_T3")) : kDeepStepsVerify;
   const int nsteps = a.kw >> (a.w8 ? 6 : 5);   // loads per wave over the whole K slice
-  const bool deep = nsteps >= (a.T >= 3 ? deep_steps_t : deep_steps);
+  const bool deep = nsteps >= (a.T >= 3 ? kDeepStepsVerify : kDeepSteps);
   if (a.w8) return deep ? launch_epi_w<EPI, true, kBatchDeep>(a, mask, grid, smem, st) : launch_epi_w<EPI, true, kBatchShallow>(a, mask, grid, smem, st);
   return deep ? launch_epi_w<EPI, false, kBatchDeep>(a, mask, grid, smem, st) : launch_epi_w<EPI, false, kBatchShallow>(a, mask, grid, smem, st);
 }

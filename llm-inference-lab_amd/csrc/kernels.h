@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include "debug_env.h"
 
 namespace sd {
 

@@ -60,6 +60,7 @@ struct PersistArgs {
   // spread over the memory-side cache slices instead of queueing on the few a dense 8-32 KiB buffer maps to
   unsigned gran_unit;
   unsigned* sync;             // [0] launch counter, [1] status (0 = ok), [2..] reserved
+  unsigned* host_status;      // optional, pinned host memory: a workgroup that gives up also stores its reason here
   const int32_t* skip_k;      // per-row adaptive K, as GemvArgs
   int skip_i;
   // LDS carve (bytes), set by launch_persist_forward
@@ -76,6 +77,8 @@ size_t persist_workspace_bytes(const sd_model_config& c);
 constexpr unsigned kGranUnitMax = 528;   // storage granules per 16-granule unit the buffers are sized for
 // static eligibility of a model (architecture, dtype, shapes); T-dependent limits are checked per pass
 bool persist_model_ok(const sd_model_config& c, bool packed, bool w8, int n_cus);
+// cache rows the attention of the persistent launch can walk (16-byte V^T vectors of 8 keys)
+inline bool persist_cache_ok(int l_max) { return l_max >= 8 && l_max % 8 == 0; }
 // tokens one pass can hold for this model (LDS: staged rows + ring), 0 = none
 int persist_max_tokens(const sd_model_config& c);
 int launch_persist_forward(PersistArgs a, hipStream_t st);

@@ -47,58 +47,25 @@
 #include "gemv_device.h"
 #include "persist.h"
 
-// ---- tuning switches (compile time; defaults = what same-box A/B runs of profiles/tools/ab_persist.sh kept) -------------
-#ifndef SD_P_CHUNK
-#define SD_P_CHUNK 16      // MFMAs per chunk: 8 -> +14 us per 1B forward, 32 -> +50 us
-#endif
-#ifndef SD_P_PIPEPOLL
-#define SD_P_PIPEPOLL 0    // two sweep passes in flight: +27 us per forward (polling traffic)
-#endif
-#ifndef SD_P_BACKOFF
-#define SD_P_BACKOFF 2     // s_sleep units after an incomplete sweep pass (0 / 2 / 8: no difference)
-#endif
-#ifndef SD_P_GWAIT
-#define SD_P_GWAIT 0       // first sweep pass only after this CU's own leader has published: +2 us per forward
-#endif
-#ifndef SD_P_SPLIT
-#define SD_P_SPLIT 2048    // rows wider than this many granules are swept by two waves (off: +15 us per forward)
-#endif
-#ifndef SD_P_THIN
-#define SD_P_THIN 1        // while this CU's gatherer sweeps the loader keeps 1 slot in flight (-10 us per forward); 2: none
-#endif
-#ifndef SD_P_THINATT
-#define SD_P_THINATT 1     // the same while an attention CU sweeps q / k / v (-4 us per forward)
-#endif
-#ifndef SD_P_LEADQKV
-#define SD_P_LEADQKV 0     // the leader multiplies in short single-tile ops whose tiles are not 1-KiB units (QKV at 6 pairs)
-#endif
-#ifndef SD_P_LEADIN_UNITS
-#define SD_P_LEADIN_UNITS 96   // the leader multiplies in single-tile ops of at least this many MFMAs per tile (down-projection)
-#endif
+// ---- fixed tuning values: what the same-box A/B runs of round 3 kept (profiles/round3_persist_ab.md has every alternative that
+// was measured: chunk 8 / 32, two sweep passes in flight, loader paused instead of thinned, three slots in flight, leader in the
+// QKV multiply, ...). Only the diagnostic build is still a compile-time switch.
 #ifndef SD_P_DIAG
 #define SD_P_DIAG 0        // diagnostic build: the timeline instance times the third consumer's MFMA part in shader cycles (slots 8-11)
-#endif
-#ifndef SD_P_INFLIGHT
-#define SD_P_INFLIGHT 2    // slots the loader keeps in flight (3: vmcnt(32), 2: vmcnt(16): -6 us per forward — shorter queues in front of the sweeps)
-#endif
-
-#ifndef SD_P_NSPLIT
-#define SD_P_NSPLIT 1      // 1-token passes: the gatherer and the third consumer each sweep + normalise HALF of a norm-fused op's input row (-5 us per forward, 6 repeats)
-#endif
-#ifndef SD_P_ATTNPF
-#define SD_P_ATTNPF 1      // attention: a wave's second cached block is in flight before it computes its first (-6 us per forward at 128 cached positions; both: -7.5)
-#endif
-#ifndef SD_P_UNIF
-// Wait loops whose give-up test is forced wave-uniform, one bit per site (see expired()): 1 wait_word, 2 loader, 4 chunk loop,
-// 8 granule sweeps, 16 attention sweep. All 32 combinations measured on one box (us per 1B forward; 0: 613): 5 -> 601, 7 -> 592,
-// 13 -> 587, 15 -> 592; every combination of 1 with 16 -> 718-754 (profiles/round3_persist_ab.md).
-#define SD_P_UNIF 13
 #endif
 
 namespace sd {
 namespace {
 
 constexpr unsigned kPiece = 1024;                        // bytes per LDS-DMA wave-instruction
+constexpr int kChunk = 16;            // MFMAs per chunk (8: +14 us per 1B forward, 32: +50 us)
+constexpr int kBackoff = 2;           // s_sleep units after an incomplete sweep pass (0 / 2 / 8: no difference)
+constexpr int kSplitSweep = 2048;     // plain rows wider than this many granules are swept by two waves (off: +15 us per forward)
+constexpr int kLeadInUnits = 96;      // the leader multiplies in single-tile ops of at least this many MFMAs per tile (down-projection)
+// Wait loops whose give-up test is forced wave-uniform, one bit per site (see expired()): 1 wait_word, 2 loader, 4 chunk loop,
+// 8 granule sweeps, 16 attention sweep. All 32 combinations were measured on one box (us per 1B forward; 0: 613): 5 -> 601,
+// 7 -> 592, 13 -> 587, 15 -> 592; every combination of 1 with 16 -> 718-754 (profiles/round3_persist_ab.md).
+constexpr unsigned kUniformSites = 13;
 constexpr unsigned kTimeoutTicks = 50u * 1000u * 100u;   // 50 ms of the 100 MHz constant clock
 constexpr int kPartT = kPersistMaxT;                     // token columns kept of a partial tile
 
@@ -117,7 +84,7 @@ struct PCtl {   // LDS control words (all written with relaxed workgroup-scope a
   unsigned a_merged;     // attention units merged
   unsigned g2_seq;       // ops whose second half of the input rows the third consumer has staged (wide rows only)
   unsigned a2_seq;       // attention units whose odd new positions the third consumer has staged (M > 1)
-  unsigned nsum[2];      // SD_P_NSPLIT: sum of squares of each half row (float bits)
+  unsigned nsum[2];      // gather_norm_half: sum of squares of each half row (float bits)
   unsigned nseq[2];      //              op whose half-row sum is in nsum
   unsigned gathering;    // the gatherer is sweeping: the loader keeps one slot in flight (its bursts queue in front of the sweep's loads)
 };
@@ -165,21 +132,26 @@ struct PCtxT {
 __device__ __attribute__((noinline)) bool expired_slow(const unsigned* abort_word, unsigned long long t_start) {
   return lds_ld(abort_word) != 0u || static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - t_start) > kTimeoutTicks;
 }
-// SITE: which wait loop asks (experiment switch SD_P_UNIF, one bit per site: 0 wait_word, 1 loader, 2 chunk loop, 3 sweeps, 4 attention sweep)
+// SITE: which wait loop asks (experiment switch kUniformSites, one bit per site: 0 wait_word, 1 loader, 2 chunk loop, 3 sweeps, 4 attention sweep)
 template <int SITE = 0, class C>
 __device__ __forceinline__ bool expired(const C& c) {
   // (the callee's result comes back in a VGPR: without the readfirstlane every exit of every wait loop is a divergent branch,
   //  and every value carried around such a loop — ring positions, piece counts, tile numbers — leaves the scalar unit)
   const bool e = expired_slow(&c.ctl->abort_, c.t_start);
-  if constexpr ((SD_P_UNIF >> SITE) & 1) return __builtin_amdgcn_readfirstlane(static_cast<int>(e)) != 0;
+  if constexpr ((kUniformSites >> SITE) & 1) return __builtin_amdgcn_readfirstlane(static_cast<int>(e)) != 0;
   else return e;
 }
-__device__ __attribute__((noinline)) void give_up_slow(unsigned* abort_word, unsigned* status, unsigned code, int lane) {
+__device__ __attribute__((noinline)) void give_up_slow(unsigned* abort_word, unsigned* status, unsigned* host_status, unsigned code, int lane) {
   lds_st(abort_word, 1u);
-  if (lane == 0) atomicOr(status, code);
+  if (lane == 0) {
+    atomicOr(status, code);
+    // the host's copy (pinned memory): readable without a stream synchronisation by whoever consumes the pass's outputs.
+    // A plain system-scope store (PCIe atomics are not a given): any non-zero value says "invalid", the device word has the OR.
+    if (host_status) __hip_atomic_store(host_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 template <class C>
-__device__ __forceinline__ void give_up(const C& c, unsigned code) { give_up_slow(&c.ctl->abort_, c.a->sync + 1, code, c.lane); }
+__device__ __forceinline__ void give_up(const C& c, unsigned code) { give_up_slow(&c.ctl->abort_, c.a->sync + 1, c.a->host_status, code, c.lane); }
 template <class C>
 __device__ __forceinline__ void stamp(const C& c, int slot) {
   if constexpr (!C::kStamps) return;
@@ -264,17 +236,6 @@ __device__ __forceinline__ void loader_role(const C& c) {
       __builtin_amdgcn_s_sleep(2);
       if ((spins & 255u) == 0u && expired<1>(c)) { give_up(c, ST_LOADER); return; }
     }
-    if (SD_P_THIN == 2) {
-      for (unsigned spins = 1; lds_ld(&c.ctl->gathering); ++spins) {
-        if (pub != issued) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          pub = issued;
-          lds_st(&c.ctl->landed, pub);
-        }
-        __builtin_amdgcn_s_sleep(2);
-        if ((spins & 255u) == 0u && expired<1>(c)) { give_up(c, ST_LOADER); return; }
-      }
-    }
     unsigned n = 0;
     if (left > 16 || (left == 16 && tail == kPiece)) {
       // a whole slot of full pieces inside one segment: the tight path (the loader must issue a slot in well under its
@@ -304,19 +265,14 @@ __device__ __forceinline__ void loader_role(const C& c) {
       }
     }
     issued += n;
-    if (SD_P_THIN && lds_ld(&c.ctl->gathering)) {
+    if (lds_ld(&c.ctl->gathering)) {   // this CU sweeps: one slot in flight (its bursts queue in front of the sweep's loads; -10 us per forward)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       pub = issued;
       lds_st(&c.ctl->landed, pub);
     } else if (n == 16 && left) {
       // every slot before this one was a full one: all but the 32 newest instructions have landed
-#if SD_P_INFLIGHT == 3
-      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      constexpr unsigned kBehind = 32u;
-#else
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // two slots in flight (three: no faster, longer queues in front of the sweeps)
       constexpr unsigned kBehind = 16u;
-#endif
       if (issued >= kBehind && issued - kBehind > pub) {
         pub = issued - kBehind;
         lds_st(&c.ctl->landed, pub);
@@ -516,7 +472,6 @@ __device__ __forceinline__ void epilogue_finish(const C& c, const OpView& o, con
 //     with its epilogue operands ready when the partials arrive, in ops of several tiles (gate/up, lm_head) its epilogue of
 //     tile i runs while the other two are in tile i + 1.
 // Returns false when the wave gave up.
-constexpr int kChunk = SD_P_CHUNK;
 
 // one chunk: UB / XS = byte strides of the weight fragments / activation fragments (0: run-time values ub / xs)
 struct ChunkDiag { unsigned long long reads, mfma, wait, spins, chunks, other; };
@@ -584,7 +539,7 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
   const bool multi = o.n_tiles > 1;
   const bool dbl0 = NP ? NP == 4 : (!multi && o.my_pairs == 4 && (o.steps & 1) == 0);
   const int units0 = dbl0 ? o.steps >> 1 : o.steps;
-  const bool lead_in = !multi && (units0 >= SD_P_LEADIN_UNITS || (SD_P_LEADQKV && o.my_pairs != 4 && o.my_pairs != 8 && units0 > kChunk));
+  const bool lead_in = !multi && units0 >= kLeadInUnits;
   const int share = lead_in ? 3 : 2;
   // (when it does multiply, the leader takes the short share: chunk 2, 5, ... of a tile)
   const int first_chunk = lead_in ? (cw + 2) % 3 : cw - 1;   // -1: this wave (the leader) does not multiply in this op
@@ -677,9 +632,9 @@ __device__ __forceinline__ bool consume_op(const C& c, int cw, const OpView& o, 
         unsigned long long* d = c.a->debug_ts + static_cast<size_t>(c.cu) * (12 * c.a->n_ops + 4) + ts_mfma + 3;
         if (!d_first) d_first = d_end;
         d[0] = d_first - d_loop0;                                   // prologue: entry -> first chunk
-        d[1] = dg.reads + dg.mfma + dg.wait;                        // LDS reads + MFMAs + waiting for weights
-        d[2] = (d_end - d_first) - (dg.reads + dg.mfma + dg.wait);  // everything else inside the chunk loop
-        d[3] = t3 - d_end;                                          // partial tile + done flag
+        d[1] = dg.reads + dg.mfma;                                  // LDS reads + MFMAs
+        d[2] = dg.wait;                                             // waiting for weights to land
+        d[3] = (t3 - d_first) - (dg.reads + dg.mfma + dg.wait);     // everything else inside the chunk loop + partial tile + done flag
       }
     }
     if (LEAD) {
@@ -727,7 +682,7 @@ __device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base
       const int idx = k * 1024 + j * 64 + c.lane;
       p[k][j] = base + granule_slot(a, first + static_cast<unsigned>(idx < count ? idx : count - 1));
     }
-  unsigned long long xa[NC][LPC], xb[NC][LPC];
+  unsigned long long xa[NC][LPC];
   auto issue = [&](unsigned long long (&x)[NC][LPC]) {
 #pragma unroll
     for (int k = 0; k < NC; ++k)
@@ -745,26 +700,12 @@ __device__ __forceinline__ bool sweep(const C& c, const unsigned long long* base
       }
     return __all(ok) != 0;
   };
-#if SD_P_PIPEPOLL
-  issue(xa);
-  __builtin_amdgcn_s_sleep(8);
-  for (unsigned spins = 1;; ++spins) {
-    issue(xb);
-    __builtin_amdgcn_sched_barrier(0);
-    if (complete(xa)) return true;    // (waits for pass A only: pass B's loads are younger)
-    issue(xa);
-    __builtin_amdgcn_sched_barrier(0);
-    if (complete(xb)) return true;
-    if ((spins & 127u) == 0u && expired<3>(c)) { give_up(c, ST_GRANULE); return false; }
-  }
-#else
   for (unsigned spins = 1;; ++spins) {
     issue(xa);
     if (complete(xa)) return true;
-    __builtin_amdgcn_s_sleep(SD_P_BACKOFF);
+    __builtin_amdgcn_s_sleep(kBackoff);
     if ((spins & 255u) == 0u && expired<3>(c)) { give_up(c, ST_GRANULE); return false; }
   }
-#endif
 }
 
 // input rows of a norm-fused op (QKV, GATEUP, HEAD): gather the d_model-wide rows (granules of edge `edge`, or the
@@ -833,7 +774,7 @@ __device__ __forceinline__ bool gather_norm_rows(const C& c, const OpView& o, in
   return true;
 }
 
-// SD_P_NSPLIT, 1-token passes: half of the row per wave (me = 1: first half, 2: second half). The post-sweep arithmetic of a
+// 1-token passes: half of the row per wave (me = 1: first half, 2: second half). The post-sweep arithmetic of a
 // whole row (statistic, two roundings per element, 16 LDS stores per lane) is ~1.1 us on one wave and sits on the critical
 // path of three edges per layer; the two halves exchange their sums of squares through LDS (first half + second half in both
 // waves, so both normalise with the same factor).
@@ -927,7 +868,6 @@ __device__ __forceinline__ bool gather_plain_rows(const C& c, int layer, int edg
 }
 // rows wider than this many granules are swept by two waves (the gatherer and the third consumer, half each): a 64-load
 // pass of one wave took 3 us, and a pass that starts before the last producer has published is a pass lost
-constexpr int kSplitSweep = SD_P_SPLIT;
 
 // ---- attention of one (row b, q head h) unit, by the three consumer waves of its CU ---------------------------------
 // LDS scratch at lds_attn: q_s [M][D] bf16 | k_s [M][D] | vT_s [D][8] (V of the new positions, transposed, zero beyond M) |
@@ -973,14 +913,14 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
   u32x4 kf0[2][NKS], vf0[NDT];
   if (cw < nb_old) load_block(cw, kf0, vf0);   // in flight while q is on its way
   u32x4 kf1[2][NKS], vf1[NDT];
-  const bool second = SD_P_ATTNPF && cw + 3 < nb_old;
+  const bool second = cw + 3 < nb_old;   // a wave's second cached block is in flight before it computes its first
   if (second) load_block(cw + 3, kf1, vf1);
   // the scratch is rewritten (this unit's sweep and partials) only after the leader has merged the previous unit
   if (cw != 0 && st.att_no > 0 && !wait_word<1>(c, &c.ctl->a_merged, st.att_no, ST_ATTN)) return false;
 
   const bool pos_shared = M > 1;   // several new positions: even ones swept by the gatherer, odd ones by the third consumer
   if (cw == 1 || (cw == 2 && pos_shared)) {
-    if (SD_P_THINATT && cw == 1) lds_st(&c.ctl->gathering, 1u);
+    if (cw == 1) lds_st(&c.ctl->gathering, 1u);
     // sweep q_h, k_kvh, v_kvh of the M new positions: granule (t, pair p) holds rows (i, i + half) of head p / half.
     // 3 * half granules per position = NL loads per lane, unconditional (clamped) and all in flight (see sweep)
     constexpr int NL = (3 * (D / 2) + 63) / 64;
@@ -1046,7 +986,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
       if (!wait_word<1>(c, &c.ctl->a_seq, unit_no, ST_ATTN)) return false;
     } else {
       if (pos_shared && !wait_word<1>(c, &c.ctl->a2_seq, unit_no, ST_ATTN)) return false;
-      if (SD_P_THINATT) lds_st(&c.ctl->gathering, 0u);
+      lds_st(&c.ctl->gathering, 0u);
       lds_st(&c.ctl->a_seq, unit_no);
       if (!SD_P_DIAG) stamp(c, ts + 10);   // diagnostic: q / new k / new v staged
     }
@@ -1119,7 +1059,7 @@ __device__ __forceinline__ bool attention_unit(const C& c, int cw, int layer, in
 
   if (cw < nb_old) block(kf0, vf0, pos0 - cw * 32, false);
   if (second) block(kf1, vf1, pos0 - (cw + 3) * 32, false);
-  for (int blk = cw + (SD_P_ATTNPF ? 6 : 3); blk < nb_old; blk += 3) {
+  for (int blk = cw + 6; blk < nb_old; blk += 3) {
     u32x4 kf[2][NKS], vf[NDT];
     load_block(blk, kf, vf);
     block(kf, vf, pos0 - blk * 32, false);
@@ -1241,18 +1181,14 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
     //      One call site per routine: see consume_op on code size.
     const bool normed = o.kind == POP_QKV || o.kind == POP_GATEUP || o.kind == POP_HEAD;
     if (cw == 1) stamp(c, 12 * i + 0);
-    if (SD_P_THIN && cw == 1) lds_st(&c.ctl->gathering, 1u);
+    if (cw == 1) lds_st(&c.ctl->gathering, 1u);
     bool ok = true;
-#if SD_P_GWAIT
-    // the workgroups run in near lockstep: before this CU's own leader has published the previous op, no sweep can complete
-    if (cw != 0 && !wait_word<1>(c, &c.ctl->lead_done, st.tile_no, ST_PART)) return;
-#endif
     // One token: the gatherer stages the row (the third consumer sweeps the second half of wide plain rows). Several tokens:
     // the rows go alternately to the gatherer and the third consumer, so a second token costs no second round of sweeps
     // (measured before: every gather of a 2-token pass took 1.6-2x the 1-token time, +10 us per layer).
     const bool rows_shared = c.T > 1;
     if (normed) {
-      const bool halves = SD_P_NSPLIT && !rows_shared && (a.d_model & 255) == 0;   // (half a row in whole 64-granule sweeps)
+      const bool halves = !rows_shared && (a.d_model & 255) == 0;   // (half a row in whole 64-granule sweeps)
       if (cw == 1 || (cw == 2 && (rows_shared || halves))) {
         const int edge = (o.kind == POP_GATEUP) ? PE_X2 : PE_X;   // the head reads the rows the last down-projection left (layer index n_layers)
         const bool emb = (o.kind == POP_QKV && o.layer == 0) || (o.kind == POP_HEAD && a.n_layers == 0);
@@ -1276,7 +1212,7 @@ __device__ __forceinline__ void consumer_role(const C& c, int cw) {
     }
     if (!ok) return;
     if (cw == 1) {
-      if (SD_P_THIN) lds_st(&c.ctl->gathering, 0u);
+      lds_st(&c.ctl->gathering, 0u);
       lds_st(&c.ctl->u_seq, static_cast<unsigned>(i + 1));
       stamp(c, 12 * i + 1);
     } else if (cw == 2) {
@@ -1362,9 +1298,13 @@ __global__ __launch_bounds__(256) void persist_forward_kernel(const PersistArgs 
     d[2] = __builtin_amdgcn_s_memrealtime();
     d[3] = __builtin_amdgcn_s_memtime();
   }
-  // the next launch's tags: advanced by workgroup 0's leader whether or not this launch completed (every workgroup read
-  // the counter at entry, long before any workgroup can get here)
-  if (blockIdx.x == 0 && wave == 1 && c.lane == 0) __hip_atomic_store(a.sync, (launch + 1u) & 0x7fffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The next launch's tags: advanced by workgroup 0's leader when the launch COMPLETED. Its leader can only get here after
+  // every workgroup has published its share of the last edge, i.e. after every workgroup has read the counter at entry. A launch
+  // that gave up leaves the counter alone: a workgroup of it that is scheduled late (the CUs were shared with another kernel)
+  // must not pick up the next launch's tags; sd_model_engine_status_clear moves the counter past the failed launch from the
+  // host, after the stream has drained.
+  if (blockIdx.x == 0 && wave == 1 && c.lane == 0 && lds_ld(&c.ctl->abort_) == 0u)
+    __hip_atomic_store(a.sync, (launch + 1u) & 0x7fffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr size_t kLdsBytes = 160 * 1024;
@@ -1400,7 +1340,7 @@ static LdsPlan plan_lds(int d_model, int HqD, int d_ff, int head_dim, int T, int
 }  // namespace
 
 bool persist_model_ok(const sd_model_config& c, bool packed, bool w8, int n_cus) {
-  if (getenv("SPECDEC_NO_PERSIST")) return false;
+  if (getenv(debug_env::kNoPersist)) return false;
   if (c.arch != SD_ARCH_LLAMA || !packed || w8 || n_cus != kPersistCUs) return false;
   if (c.head_dim != 64 && c.head_dim != 128) return false;
   const int HqD = c.n_heads * c.head_dim;
@@ -1444,14 +1384,17 @@ size_t persist_workspace_bytes(const sd_model_config& c) {
 
 template <int D, int HC, bool STAMPS, bool SEL, bool TAPS>
 static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (the attribute is per device: a process that drives several GPUs sets it on each)
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  SD_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !((attr_set >> dev) & 1ull)) {
     SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(kLdsBytes)));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set |= 1ull << dev;
   }
   // test hook (tests/test_hip_persist_gpu.py): one workgroup short, so granules are missing and every bounded wait has to expire
-  const int grid = getenv("SPECDEC_PERSIST_TEST_DROP_WG") ? kPersistCUs - 1 : kPersistCUs;
+  const int grid = getenv(debug_env::kPersistDropWg) ? kPersistCUs - 1 : kPersistCUs;
   hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), dim3(grid), dim3(256), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
@@ -1467,6 +1410,8 @@ int launch_persist_forward(PersistArgs a, hipStream_t st) {
   const int T = a.B * a.M;
   SD_REQUIRE(T >= 1 && T <= kPersistMaxT && a.M <= 8, "persist: T=%d M=%d out of range", T, a.M);
   SD_REQUIRE(a.B * a.n_q_heads <= kPersistCUs, "persist: %d attention units exceed the CUs", a.B * a.n_q_heads);
+  // attention_unit reads V^T in 16-byte vectors of 8 keys at n * l_max + key0 and clamps to l_max - 8
+  SD_REQUIRE(a.l_max >= 8 && a.l_max % 8 == 0, "persist: cache rows of %d positions (need a multiple of 8)", a.l_max);
   const int HqD = a.n_q_heads * a.head_dim;
   const LdsPlan p = plan_lds(a.d_model, HqD, a.d_ff, a.head_dim, T, a.M);
   SD_REQUIRE(p.ok, "persist: T=%d rows do not fit the LDS next to a 64 KiB ring", T);
@@ -1480,8 +1425,7 @@ int launch_persist_forward(PersistArgs a, hipStream_t st) {
   a.u_stride = p.u_stride;
   a.resid_ppw = gemv_geometry(a.d_model / 2, HqD).ppw;
   // granule buffers inside a parity (kPersistMaxT rows each), 16-granule units at a stride of gran_unit storage granules
-  static const unsigned unit_env = getenv("SPECDEC_GRAN_UNIT") ? static_cast<unsigned>(atoi(getenv("SPECDEC_GRAN_UNIT"))) : kGranUnitMax;
-  a.gran_unit = (unit_env >= 16 && unit_env <= kGranUnitMax) ? unit_env : kGranUnitMax;
+  a.gran_unit = kGranUnitMax;   // (16 / 64 / 144 / 528 measured: no difference; every 128-byte unit in a page of its own)
   size_t off = 0;
   a.off_edge[PE_X] = static_cast<unsigned>(off); off += edge_storage(a.d_model / 2, a.gran_unit);
   a.off_edge[PE_QKV] = static_cast<unsigned>(off); off += edge_storage((a.n_q_heads + 2 * a.n_kv_heads) * a.head_dim / 2, a.gran_unit);

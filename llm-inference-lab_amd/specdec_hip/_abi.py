@@ -83,6 +83,11 @@ SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]),
     "sd_model_persist_tokens": (_c_int, [_c_void_p]),
     "sd_model_engine_status": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_uint32), _c_void_p]),
+    "sd_model_status_word": (ctypes.POINTER(ctypes.c_uint32), [_c_void_p]),
+    "sd_model_engine_status_clear": (_c_int, [_c_void_p, _c_void_p]),
+    "sd_model_set_persist_tokens": (_c_int, [_c_void_p, _c_int]),
+    "sd_model_set_length_hint": (_c_int, [_c_void_p, _c_int]),
+    "sd_model_persist_active": (_c_int, [_c_void_p, _c_int]),
     "sd_model_debug_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "sd_model_probe_forward": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_double), _c_void_p, _c_size]),
@@ -103,6 +108,7 @@ SIGNATURES = {
     "sd_specdec_sync": (_c_int, [_c_void_p, _c_void_p]),
     "sd_specdec_launches": (ctypes.c_long, [_c_void_p]),
     "sd_specdec_wait": (_c_int, [_c_void_p, ctypes.c_long]),
+    "sd_specdec_invalidate": (_c_int, [_c_void_p]),
     "sd_specdec_record": (ctypes.POINTER(ctypes.c_int32), [_c_void_p]),
     "sd_specdec_record_ints": (_c_int, [_c_void_p]),
 }

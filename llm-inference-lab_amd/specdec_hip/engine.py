@@ -49,6 +49,15 @@ def _stream(stream: Optional[torch.cuda.Stream], device) -> int:
     return (stream or torch.cuda.current_stream(device)).cuda_stream
 
 
+class EngineGaveUp(_abi.HipLibraryError):
+    """A persistent forward hit one of its bounded waits (another kernel held CUs it needs, or a workgroup never ran) and left.
+    Nothing hangs and nothing is silently wrong: the health word says so, the caller repeats the work on the launch path."""
+
+    def __init__(self, msg: str, status: int = 0):
+        super().__init__(msg)
+        self.status = status
+
+
 class HipModel:
     """A decoder (Llama or GPT-2 shaped) bound to its KV cache on one GPU."""
 
@@ -193,6 +202,8 @@ class HipModel:
         assert pos_base.dtype == torch.int32 and pos_base.shape == (tokens.shape[0],) and pos_base.device == self.device
         B, M = tokens.shape
         tokens = tokens.contiguous()
+        if self.health():                 # an earlier persistent pass gave up: do not pile more work on invalid rows
+            self.check_health("sd_model_forward")
         if self.page_len is not None:     # paged KV: the positions this pass writes must have pages (host-known here at the cost
             for i, p0 in enumerate(pos_base.tolist()):   # of one read-back; the captured step loop reserves ahead instead)
                 self.reserve(row0 + i, p0 + int(pos_off) + M, stream=stream)
@@ -238,6 +249,56 @@ class HipModel:
     def persist_tokens(self) -> int:
         """Tokens per pass that run as ONE persistent launch (sd_model_persist_tokens); 0 = launch-per-operator only."""
         return int(self.lib.sd_model_persist_tokens(self.handle))
+
+    def persist_active(self, tokens: int = 1) -> bool:
+        """Would a pass of `tokens` tokens of one row run as the persistent launch right now (token limit, length hint, paging)?"""
+        return bool(self.lib.sd_model_persist_active(self.handle, int(tokens)))
+
+    def set_persist_tokens(self, max_tokens: int) -> None:
+        """Tokens per pass the persistent launch takes from now on (0: launch path only; sd_model_set_persist_tokens). Loops that
+        captured a step over this model must be invalidated (HipSpecDec.invalidate)."""
+        _abi.check(self.lib.sd_model_set_persist_tokens(self.handle, int(max_tokens)), "sd_model_set_persist_tokens")
+
+    def set_length_hint(self, max_len: Optional[int]) -> None:
+        """The caller's bound on the current length of the rows the coming passes touch (None: the cache size). The persistent
+        launch serves rows of up to 1536 positions (sd_model_set_length_hint)."""
+        _abi.check(self.lib.sd_model_set_length_hint(self.handle, int(max_len or 0)), "sd_model_set_length_hint")
+
+    def health(self) -> int:
+        """The persistent launches' health word as the pinned host copy holds it — no copy, no synchronisation: valid for every
+        pass the caller has already synchronised with (it has read the pass's ids / logits). 0 = all completed."""
+        w = getattr(self, "_status_word", None)
+        if w is None:
+            ptr = self.lib.sd_model_status_word(self.handle)
+            if not ptr:
+                return 0
+            w = self._status_word = np.ctypeslib.as_array(ptr, shape=(1,))
+        return int(w[0])
+
+    def check_health(self, what: str = "forward", sync: bool = False, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Raise EngineGaveUp when a persistent launch of this model gave up (its outputs, and those of every pass after it, are
+        invalid). sync: drain `stream` first (for a caller that has not yet read anything of its last pass)."""
+        if sync:
+            (stream or torch.cuda.current_stream(self.device)).synchronize()
+        st = self.health()
+        if st:
+            raise EngineGaveUp(f"{what}: a persistent forward gave up (status {st:#x}: see sd_model_engine_status); the outputs since "
+                               "then are invalid — HipModel.recover() clears the word and continues on the launch path", st)
+
+    def recover(self, stream: Optional[torch.cuda.Stream] = None) -> int:
+        """After a give-up: drain the stream, clear the health word (device and host), move the launch counter past the failed
+        launch, and switch this model to the launch path (persistent passes stay off until the model is bound again or
+        set_persist_tokens re-enables them). The passes since the failure must be repeated. Returns the status that was cleared."""
+        st = self.engine_status(stream)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_model_engine_status_clear(self.handle, _stream(stream, self.device)), "sd_model_engine_status_clear")
+        self.set_persist_tokens(0)
+        return st
+
+    def clear_engine_status(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """sd_model_engine_status_clear alone: the persistent path stays on (tests of the give-up path)."""
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_model_engine_status_clear(self.handle, _stream(stream, self.device)), "sd_model_engine_status_clear")
 
     def engine_status(self, stream: Optional[torch.cuda.Stream] = None) -> int:
         """0 = every persistent launch of this model completed (sd_model_engine_status; synchronises the stream)."""
@@ -302,8 +363,8 @@ class StepRecord:
         # health word of the models' persistent launches (sd_model_engine_status): a launch that gave up leaves garbage
         self.engine_status = int(arr[0, 6 + 3 * K]) if arr.shape[1] > 6 + 3 * K else 0
         if self.engine_status:
-            raise _abi.HipLibraryError(f"a persistent forward gave up (status {self.engine_status:#x}: see sd_model_engine_status); "
-                                       "the step's outputs are invalid")
+            raise EngineGaveUp(f"a persistent forward gave up (status {self.engine_status:#x}: see sd_model_engine_status); "
+                               "the step's outputs are invalid", self.engine_status)
 
 
 class HipSpecDec:
@@ -447,6 +508,17 @@ class HipSpecDec:
     @property
     def launches(self) -> int:
         return int(self.lib.sd_specdec_launches(self.handle))
+
+    def invalidate(self) -> None:
+        """Drop the captured step (a model's path changed: set_persist_tokens / set_length_hint / a re-bind). The caller has
+        drained the loop; the next step runs eagerly, the one after it captures again (sd_specdec_invalidate)."""
+        _abi.check(self.lib.sd_specdec_invalidate(self.handle), "sd_specdec_invalidate")
+
+    def drain(self) -> None:
+        """Wait for everything launched, without reading a record (recovery path: the records may be invalid)."""
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.sd_specdec_sync(self.handle, self.stream_t.cuda_stream), "sd_specdec_sync")
+            _abi.check(self.lib.sd_specdec_sync(self.handle, self.stream_d.cuda_stream), "sd_specdec_sync")
 
     def wait(self, launch_index: int) -> StepRecord:
         """Wait for one of the last two launched steps (the other may still be running) and return its record."""

@@ -32,7 +32,7 @@ import psutil
 import torch
 import yaml
 
-from specdec_hip.engine import HipModel, HipSpecDec
+from specdec_hip.engine import EngineGaveUp, HipModel, HipSpecDec
 
 from ..models.hip_lm import HipLM, create_hip_lm
 from ..policies.controllers import create_controller
@@ -68,11 +68,12 @@ def _clamp(tok: int, vocab: int) -> int:
 
 
 class _Row:
-    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws", "steps", "strict_acc", "strict_prop", "k_trace")
+    __slots__ = ("seq", "generated", "active", "proposed", "accepted", "draws", "steps", "strict_acc", "strict_prop", "k_trace", "counters")
 
     def __init__(self, seq: List[int]):
         self.seq, self.generated, self.active = seq, [], True
         self.proposed = self.accepted = self.draws = self.steps = 0
+        self.counters: List[tuple] = []            # after each of the row's own steps: (proposed, accepted, tokens generated, accept length)
         self.strict_acc = self.strict_prop = 0     # per-row adaptive K: what the row's controller is fed with
         self.k_trace: List[int] = []               # ... and the k that counted in each of its steps
 
@@ -738,6 +739,21 @@ class DecodeSession:
 
         self._queue = deque()                # launched, not yet consumed: (launch index, set of rows it is void for)
         self._flagged: Dict[int, str] = {}   # rows whose device state must be repaired before the next launch
+        # The persistent draft forward serves rows of up to 1536 positions (one CU walks a head's whole cache); a session whose
+        # cache is sized for more starts on it all the same: every launch point tells the engines how far the rows can have
+        # got by the end of the step (sd_model_set_length_hint), and when that moves a model to the other path the queue is
+        # drained once and the step captured again (the captured kernels are correct at any length, only slower past the bound).
+        self._hint()
+
+    def _reach(self) -> int:
+        """Positions the steps in flight plus one more can have reached on the longest row."""
+        return max(len(r.seq) for r in self.rows) + (len(self._queue) + 2) * (self.k + 1) + 2
+
+    def _hint(self) -> tuple:
+        reach = self._reach()
+        for e in self._engines:
+            e.set_length_hint(reach)
+        return tuple(e.persist_active(1) for e in self._engines)
 
     def any_active(self) -> bool:
         return any(r.active for r in self.rows)
@@ -792,6 +808,24 @@ class DecodeSession:
                 loop.set_adaptive_row(b, m.current_k, r.strict_acc, r.strict_prop, m.acceptance_history[-4:])
         self._flagged.clear()
 
+    def _recover(self, err: Exception) -> None:
+        """A persistent launch of one of the models gave up (its bounded waits expired: the CUs were shared with another
+        kernel). Every step since is void: drain the loop, clear the engines' health words and move them to the launch path
+        (HipModel.recover), drop the captured step, rebuild every active row's caches from the host's sequences. Twice in one
+        session: give up for real."""
+        n = self.stats["engine_recoveries"] = self.stats.get("engine_recoveries", 0) + 1
+        if n > 2:
+            raise err
+        self.pipe.logger.warning("decode session: %s — continuing on the launch path", err)
+        self.loop.drain()
+        self._queue.clear()
+        for e in self._engines:
+            e.recover(self.loop.stream_t)
+        self.loop.invalidate()
+        self.loop._captured_paths = None
+        for b, r in enumerate(self.rows):
+            self._flagged[b] = "resync" if r.active else "freeze"
+
     @property
     def _inflight(self) -> bool:
         return bool(self._queue)
@@ -804,6 +838,14 @@ class DecodeSession:
             if getattr(self, "_resample_state", False):
                 self._resample_state = False
                 self._apply_sampling()
+        if not self._queue:
+            paths = self._hint()
+            was = getattr(self.loop, "_captured_paths", None)
+            if was is not None and was != paths:      # a model changed path (rows passed the persistent launch's context bound)
+                self.loop.drain()
+                self.loop.invalidate()
+                self.stats["path_switches"] = self.stats.get("path_switches", 0) + 1
+            self.loop._captured_paths = paths
         idx = self.loop.launches
         if self._engines[0].page_len is not None:
             # paged KV: the device advances by itself, so every row gets the pages of all the steps in flight plus this one
@@ -820,6 +862,8 @@ class DecodeSession:
         """Conservative: some row cannot finish within the steps already launched, and nothing waits for a repair."""
         if self._flagged or getattr(self, "_resample_state", False):
             return False
+        if self._hint() != getattr(self.loop, "_captured_paths", None):
+            return False                   # a path switch is due: the queue drains first (_launch re-captures)
         ahead = len(self._queue) + 1       # steps whose records are still to come, counting the one being considered
         per_step = self.k + 1 if self.emit_mode == HipSpecDec.EMIT_BONUS else self.k
         for b, r in enumerate(self.rows):
@@ -863,7 +907,11 @@ class DecodeSession:
         while self._early and len(self._queue) < self._depth and self._can_launch_ahead():
             self._launch()              # keep the GPU's queue ahead of the host
         idx, void = self._queue.popleft()
-        rec = loop.wait(idx) if self._queue else loop.sync()
+        try:
+            rec = loop.wait(idx) if self._queue else loop.sync()
+        except EngineGaveUp as e:
+            self._recover(e)
+            return True                 # nothing was taken from the void steps; the rows rejoin at the next launch
         self.last_record = rec
         while self._early and len(self._queue) < self._depth and self._can_launch_ahead():
             self._launch()              # step s+1 (s+2) runs while the rules of step s are applied below
@@ -898,6 +946,9 @@ class DecodeSession:
             else:
                 pipe._rules_single(r, k, a, d, t, self.max_tokens, self.eos)
             r.steps += 1
+            r.counters.append((r.proposed, r.accepted, len(r.generated), a))
+            if a >= k:
+                stats["full_accepts"] = stats.get("full_accepts", 0) + 1
             stats["proposed"] += k
             stats["accepted"] += r.accepted - acc0
             if r.active and self.step_limit is not None and r.steps >= self.step_limit:

@@ -19,7 +19,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from specdec_hip import weights as W
-from specdec_hip.engine import HipModel
+from specdec_hip.engine import EngineGaveUp, HipModel
 
 from ..cache.kv_types import KVCache
 from ..utils.interfaces import LanguageModel
@@ -86,9 +86,32 @@ class HipLM(LanguageModel):
             self._cached = [[] for _ in range(m.batch)]
         return m
 
+    # ---- health of the persistent launches behind the plain-forward path -----------------------------------------------
+    def _guarded(self, what: str, body):
+        """Run `body()` (forwards of self._model, returning device tensors), then check the engine's health word once the stream
+        has drained. A persistent launch that gave up (EngineGaveUp: its bounded waits expired — typically another kernel held
+        CUs it needs) invalidates what it wrote: the model moves to the launch path (HipModel.recover), the cached prefixes are
+        forgotten (their K/V rows may hold garbage) and the call is repeated once. Nothing is returned from an invalid pass."""
+        for attempt in (0, 1):
+            try:
+                out = body()
+                if self._model is not None:
+                    self._model.check_health(what, sync=True)
+                return out
+            except EngineGaveUp as e:
+                if attempt or self._model is None:
+                    raise
+                logger.warning("%s: %s — repeating on the launch path", what, e)
+                self._model.recover()
+                self._cached = [[] for _ in self._cached]
+
     # ---- LanguageModel -----------------------------------------------------------------
     def generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, temperature: float = 0.7,
                         do_sample: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._guarded("generate_tokens", lambda: self._generate_tokens(input_ids, max_new_tokens, temperature, do_sample, **kwargs))
+
+    def _generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, temperature: float = 0.7,
+                         do_sample: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """k tokens + their logits [B, k, V] (fp32), one forward per token
         (hf_wrappers.py:272-627 semantics: argmax of the last position; with do_sample the
         token is drawn from softmax(logits / T)). `row=b, rows=n` (one sequence): use cache row b of an n-row engine, so
@@ -103,6 +126,7 @@ class HipLM(LanguageModel):
                 raise ValueError("generate_tokens(row=...) takes one sequence")
             return self._generate_row(ids, max_new_tokens, row0, int(kwargs.get("rows") or row0 + 1))
         m = self._engine(B, L + max_new_tokens + 1)
+        m.set_length_hint(L + max_new_tokens + 1)    # rows of this call stay below it: persistent 1-token passes up to 1536 positions
         host = ids.cpu().tolist()
         dev = self._device
         out_ids, out_logits = [], []
@@ -142,6 +166,7 @@ class HipLM(LanguageModel):
         """Greedy generate_tokens of ONE sequence in cache row b (prefix reuse per row)."""
         L = ids.shape[1]
         m = self._engine(rows, L + k + 1)
+        m.set_length_hint(L + k + 1)
         dev = self._device
         host = ids[0].cpu().tolist()
         have = self._cached[b]
@@ -170,6 +195,9 @@ class HipLM(LanguageModel):
         return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
 
     def last_hidden_state(self, input_ids: torch.Tensor, row: int = 0, rows: int = 1) -> torch.Tensor:
+        return self._guarded("last_hidden_state", lambda: self._last_hidden_state(input_ids, row, rows))
+
+    def _last_hidden_state(self, input_ids: torch.Tensor, row: int = 0, rows: int = 1) -> torch.Tensor:
         """`outputs.hidden_states[-1][:, -1:]` of the reference's draft modes (pipeline.py:674-686): the hidden state of
         the LAST token after the final norm, fp32 [1][1][d] with bf16-representable values. The prefix is cached as in
         generate_tokens; one 1-token forward with the head skipped leaves the residual row (sd_model_hidden_rows), and
@@ -193,13 +221,16 @@ class HipLM(LanguageModel):
         return h.view(1, 1, -1)
 
     def verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor, row: Optional[int] = None, rows: int = 1):
+        return self._guarded("verify_tokens", lambda: self._verify_tokens(input_ids, draft_tokens, row, rows))
+
+    def _verify_tokens(self, input_ids: torch.Tensor, draft_tokens: torch.Tensor, row: Optional[int] = None, rows: int = 1):
         """The K-token parallel verify as a wrapper call: one forward over
         (last, d_1..d_K) -> (argmax ids [B, K+1], logits [B, K+1, V]). `row` (one sequence): cache row to use."""
         ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
         B, L = ids.shape
         dev = self._device
         if row is None:
-            self.generate_tokens(ids, 0)  # caches the prefix
+            self._generate_tokens(ids, 0)  # caches the prefix
             row0 = 0
         else:
             self._generate_row(validate_and_clamp_tokens(ids.long(), self.vocab_size, "verify_tokens"), 0, row, max(rows, row + 1))

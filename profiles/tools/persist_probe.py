@@ -90,8 +90,8 @@ def main():
             for k, v in tot.items():
                 print(f"  {k:7s} " + "  ".join(f"{name} {np.mean([r[name] for r in v]):6.2f}" for name in ("gather", "w3wait", "mfma", "lead_mfma", "epi", "total")) + f"   (x{len(v)})")
                 if a.diag:
-                    print(f"          third consumer, shader cycles per op: prologue {np.mean([r['c_pre'] for r in v]):7.0f} | LDS reads + MFMAs + weight waits "
-                          f"{np.mean([r['c_body'] for r in v]):7.0f} | rest of the chunk loop {np.mean([r['c_loop'] for r in v]):7.0f} | partial + done flag {np.mean([r['c_tail'] for r in v]):7.0f}")
+                    print(f"          third consumer, shader cycles per op: prologue {np.mean([r['c_pre'] for r in v]):7.0f} | LDS reads + MFMAs "
+                          f"{np.mean([r['c_body'] for r in v]):7.0f} | waiting for weights {np.mean([r['c_loop'] for r in v]):7.0f} | rest of the chunk loop + partial + done flag {np.mean([r['c_tail'] for r in v]):7.0f}")
                 else:
                     print(f"          sweep returned {np.nanmean([r['sweep'] for r in v]):5.2f} after gather start | partials in {np.nanmean([r['parts'] for r in v]):5.2f} after staged | "
                           f"epilogue+publish {np.nanmean([r['fin'] for r in v]):5.2f} | attention: q staged {np.nanmean([r['a_stage'] for r in v]):5.2f} after op_done, "

@@ -123,3 +123,33 @@ def test_device_selected_first_draft_forward_changes_nothing(full_pair, monkeypa
     assert runs[True] == runs[False]
     _, steps, proposed, accepted = runs[True]
     assert steps < accepted < steps * (k + 1), "the run must mix fully and partly accepted steps"
+
+
+def test_persistent_draft_proposes_what_the_launch_path_proposes(full_pair, monkeypatch):
+    """The output of greedy speculative decoding is the target's continuation whatever the draft proposes, so the tests above
+    cannot see a persistent draft forward (csrc/persist.hip) that proposed worse tokens — only acceptance would drop. Here the
+    PROPOSALS are pinned at full size: the same run with the draft on the persistent launch (default: 1- and 2-token passes of
+    the 1B model) and with every draft pass on the launch path (SPECDEC_PERSIST_MAX_T=0, read when an engine binds its cache)
+    must agree on tokens, steps, proposed and accepted, and on every step's accept length — a different proposal anywhere changes
+    an accept length. What the reference compares at this boundary: LongestPrefixPolicy.accept_tokens,
+    /root/reference/src/specdec/policies/policies.py:156-180."""
+    from src.specdec import SpeculativePipeline
+
+    draft_lm, target_lm = full_pair
+    prompts = synthetic_prompts(1, 32, target_lm.vocab_size, seed=5).tolist()
+    k, runs = 4, {}
+    for persist in (True, False):
+        if not persist:
+            monkeypatch.setenv("SPECDEC_PERSIST_MAX_T", "0")
+        pipe = SpeculativePipeline(base_lm=target_lm, draft_lm=draft_lm, controller="fixed", controller_params={"k": k}, seed=1234)
+        sess = pipe.start_session(prompts, max_tokens=96, emit_mode=0)
+        assert bool(sess.rt["draft"].persist_active(1)) == persist
+        while sess.any_active() and sess.advance():
+            pass
+        sess.finish()
+        r = sess.rows[0]
+        runs[persist] = (list(r.generated), r.steps, r.proposed, r.accepted, [c[3] for c in r.counters])
+    monkeypatch.delenv("SPECDEC_PERSIST_MAX_T")
+    assert runs[True] == runs[False]
+    lens = runs[True][4]
+    assert 0 < sum(1 for a in lens if a == k) < len(lens), "the run must mix fully and partly accepted steps"

@@ -16,8 +16,15 @@ Tolerances, stated: at every depth d the logits of three new positions behind a 
 i.e. a per-layer relative error budget of 0.22 % on top of 0.8 % for the head. Measured (round 3, printed by the test): the
 error grows like a random walk, ~sqrt(d): 1B 0.8 % (2 layers) -> 2.0 % (16); 3B 0.8 % -> 3.2 % (28); 8B 0.9 % -> 4.5 % (32),
 fp8 storage 4.7 %; the largest single logit error 9 % / 19 % / 26 % of RMS(logits). A wrong layer is O(1).
-Greedy run: tokens must agree up to the first position where the oracle's top-2 margin is below 4 x the measured max logit
-error of the full-depth model; a divergence at a larger margin fails."""
+Greedy run: tokens must agree up to the first position where the oracle's top-2 margin is below 6 x the measured RMS logit
+error of the full-depth model; a divergence at a larger margin fails. (Why 6 x e_rms and not a multiple of the MAX error: a flip
+between tokens a and b needs |err_a - err_b| > margin with both errors of the size of e_rms — the difference of two of them has
+standard deviation sqrt(2) e_rms, so 6 e_rms is a > 4 sigma event; the largest error over 128256 x 3 logits is a 5-6 sigma
+outlier of the same distribution and a band built on it (round 3: 4 x e_max = 0.75 / 1.02 x RMS(logits) at 3B / 8B) admitted
+every margin that occurs. Bands now: 1B 0.12, 3B 0.19, 8B 0.27 x RMS(logits).)
+Run time: the CPU oracle's forwards dominate, so the depth sweep is {2, L} (round 3 also ran L / 2: the sqrt(d) growth is on
+file in profiles/round3 logs and in DESIGN section 4) and the greedy runs are as long as the first divergence seen in round 3
+needs (1B: token 7, 3B: token 14)."""
 
 import dataclasses
 
@@ -32,10 +39,10 @@ pytestmark = pytest.mark.gpu
 
 MODELS = {
     # name: (config, weight dtype, tokens of the greedy run)
-    "llama-3.2-1b-16L": (W.LLAMA_3_2_1B, "bf16", 32),
-    "llama-3.2-3b-28L": (W.LLAMA_3_2_3B, "bf16", 24),
-    "llama-3-8b-32L-bf16": (W.LLAMA_3_8B, "bf16", 8),
-    "llama-3-8b-32L-fp8": (W.LLAMA_3_8B, "fp8", 8),
+    "llama-3.2-1b-16L": (W.LLAMA_3_2_1B, "bf16", 16),
+    "llama-3.2-3b-28L": (W.LLAMA_3_2_3B, "bf16", 18),
+    "llama-3-8b-32L-bf16": (W.LLAMA_3_8B, "bf16", 6),
+    "llama-3-8b-32L-fp8": (W.LLAMA_3_8B, "fp8", 6),
 }
 PREFIX, NEW = 12, 3
 
@@ -67,7 +74,7 @@ def test_full_depth_logits_and_first_divergence(name):
     seq = torch.randint(4, cfg.vocab, (1, PREFIX + NEW), generator=g)
 
     # ---- (a) error against depth
-    depths = sorted({2, L // 2, L})   # (the CPU oracle's forwards are the slow part of this test)
+    depths = [2, L]   # (the CPU oracle's forwards are the slow part of this test)
     rows = []
     for d in depths:
         lm = OracleLM(_truncate(mw_cpu, d), "bf16")
@@ -87,7 +94,8 @@ def test_full_depth_logits_and_first_divergence(name):
         bound = 0.008 + 0.0022 * d
         print(f"[fulldepth]   depth {d:3d}: rms {e_rms:.4f}  max {e_max:.4f}   (bounds {bound:.4f} / {4 * bound:.4f})")
         assert e_rms <= bound and e_max <= 4 * bound, (name, d, e_rms, e_max)
-    full_max = rows[-1][1]
+    full_max, full_rms = rows[-1][1], rows[-1][2]
+    band = 6 * full_rms   # see the module docstring
 
     # ---- (b) greedy decode: first divergence and the oracle's top-2 margin there
     lm = OracleLM(mw_cpu, "bf16")
@@ -111,16 +119,16 @@ def test_full_depth_logits_and_first_divergence(name):
     margins = ((top2[:, 0] - top2[:, 1]) / rms_logit).tolist()       # oracle's top-2 margin per position, in units of RMS(logits)
     if first is None:
         print(f"[fulldepth]   greedy: all {n_greedy} tokens equal the oracle's; smallest oracle top-2 margin on the way "
-              f"{min(margins):.4f} x RMS(logits) (device max logit error {full_max:.4f})")
+              f"{min(margins):.4f} x RMS(logits) (device rms / max logit error {full_rms:.4f} / {full_max:.4f}, flip band {band:.4f})")
     else:
         print(f"[fulldepth]   greedy: first divergence at token {first} of {n_greedy}: device {got[first]} vs oracle {want[first]}, "
-              f"oracle top-2 margin there {margins[first]:.4f} x RMS(logits) (device max logit error {full_max:.4f}); "
+              f"oracle top-2 margin there {margins[first]:.4f} x RMS(logits) (device rms / max logit error {full_rms:.4f} / {full_max:.4f}, flip band {band:.4f}); "
               f"smallest margin before it {min(margins[:first], default=float('nan')):.4f}")
-        # a flip is admissible only between near-ties: margin within 4 x the measured logit error of this model
-        assert margins[first] <= 4 * full_max, (name, first, margins[first], full_max)
+        # a flip is admissible only between near-ties: margin within 6 x the measured RMS logit error of this model
+        assert margins[first] <= band, (name, first, margins[first], full_rms)
         # and the token the device picked must itself be a near-tie of the oracle's maximum (bf16 logits tie many ways)
         gap = (want_logits[0, first].max() - want_logits[0, first, got[first]]).item() / rms_logit
-        assert gap <= 4 * full_max, (name, first, gap, full_max)
+        assert gap <= band, (name, first, gap, full_rms)
 
 
 def test_full_depth_8b_specdec_is_the_targets_greedy_continuation():
