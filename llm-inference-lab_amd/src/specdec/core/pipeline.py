@@ -34,7 +34,7 @@ import yaml
 
 from specdec_hip.engine import EngineGaveUp, HipModel, HipSpecDec
 
-from ..models.hip_lm import HipLM, create_hip_lm
+from ..models.hip_lm import HipLM, create_hip_lm, create_hip_pair
 from ..policies.controllers import create_controller
 from ..policies.policies import create_policy
 from ..utils.deterministic import ensure_deterministic, set_deterministic_mode
@@ -95,10 +95,13 @@ class SpeculativePipeline:
             if val is not None:
                 self.config[key] = val
         impl = self.config["implementation"]
-        if impl not in ("hip", "hf"):
-            # "fake" (FakeLM test double) and CPU/MPS implementations of the reference have no
-            # counterpart here: the product is the GPU path
+        if impl not in ("hip", "hf", "fake"):
+            # CPU / MPS implementations of the reference have no counterpart here: the product is the GPU path
             raise ValueError(f"implementation={impl!r} is not available in this build (use 'hip')")
+        # "fake": the reference's weight-less test double (models/fake_lm.py; what the reference's own configs/specdec.yaml
+        # selects): token ids are a function of the input ids, logits are noise on the device; drives the step loop, the
+        # policies and the registry ops without a model (generate / generate_batch through the host-policy loop)
+        self._fake = impl == "fake"
         mode = self.config.get("draft_mode", "vanilla")
         # persistent heads (specdec_hip.weights.MedusaHeads): not in the reference — K trained/tied heads evaluated
         # in K GEMVs over the target's last hidden state replace the draft forwards
@@ -133,10 +136,26 @@ class SpeculativePipeline:
             set_deterministic_mode(int(self.config["seed"]))
         ensure_deterministic(int(self.config.get("seed") or 1234))
 
-        self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
+        if self._fake:
+            from ..models.fake_lm import create_fake_lm
+
+            if mode != "vanilla" or medusa_heads is not None:
+                raise NotImplementedError("implementation='fake' drafts with the fake draft model (draft_mode='vanilla')")
+            sd = self.config.get("seed")
+            self.base_lm = base_lm if base_lm is not None else create_fake_lm(f"fake-base-{self.config['base_model']}", seed=sd)
+            self.draft_lm = draft_lm if draft_lm is not None else create_fake_lm(f"fake-draft-{self.config['draft_model']}", seed=sd)
+        else:
+            self.base_lm = base_lm if base_lm is not None else None
         no_draft = mode in ("medusa", "eagle") and draft_lm is None and self.config.get("draft_model") in (None, "", "none", "NONE")
-        self.draft_lm = draft_lm if (draft_lm is not None or no_draft) else create_hip_lm(self.config["draft_model"])
+        if not self._fake:
+            if base_lm is None and draft_lm is None and not no_draft:
+                self.base_lm, self.draft_lm = create_hip_pair(self.config["base_model"], self.config["draft_model"])
+            else:
+                self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
+                self.draft_lm = draft_lm if (draft_lm is not None or no_draft) else create_hip_lm(self.config["draft_model"])
         for who, lm in (("base", self.base_lm), ("draft", self.draft_lm)):
+            if self._fake:
+                break
             if lm is None and who == "draft":
                 continue                         # Medusa-lite drafts from the target itself (generate() only)
             if not isinstance(lm, HipLM):
@@ -499,7 +518,7 @@ class SpeculativePipeline:
         max_tokens = max_tokens or self.config["max_new_tokens"]
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
-        if do_sample:
+        if do_sample and not self._fake:   # (the fake double ignores sampling parameters, in the reference as here)
             raise NotImplementedError(
                 "generate(do_sample=True): the reference lets HF sample inside the draft and the base model from the "
                 "global torch generator (pipeline.py:1019-1081); that is not restated. Use generate_batch(do_sample=True) "
@@ -509,7 +528,7 @@ class SpeculativePipeline:
         # drafts with the draft model
         if self.policy_name == "rejection":
             raise NotImplementedError("policy='rejection' is a generate_batch policy (it emits a correction / bonus token every step)")
-        if self.policy_name != "longest_prefix" or self._medusa_random():
+        if self.policy_name != "longest_prefix" or self._medusa_random() or self._fake:
             rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
                                                 temperature=float(temperature))
         else:
@@ -539,6 +558,10 @@ class SpeculativePipeline:
         step, step-count bound, no truncation to max_tokens. Rows are independent sequences."""
         if not prompts:
             return []
+        if self._fake:
+            # the double has no tokenizer to pad a batch with: the reference falls back to generate() per prompt
+            # ("No tokenizer access, falling back to sequential processing", pipeline.py:1680-1700)
+            return [self.generate(p, max_tokens=max_tokens, temperature=temperature, do_sample=do_sample, **kwargs) for p in prompts]
         max_tokens = max_tokens or self.config["max_new_tokens"]
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]

@@ -325,14 +325,72 @@ class HipLM(LanguageModel):
         return self
 
 
+_PRESETS = {"llama-3.2-1b": W.LLAMA_3_2_1B, "llama-3.2-3b": W.LLAMA_3_2_3B, "llama-3-8b": W.LLAMA_3_8B, "gpt2": W.GPT2_SMALL,
+            "distilgpt2": W.DISTILGPT2}
+# hub names the reference's configs use (configs/specdec.yaml:5-6, specdec_hf.yaml) -> the architecture preset of that model
+_HUB_NAMES = {"gpt2": "gpt2", "distilgpt2": "distilgpt2", "meta-llama/Llama-3.2-1B": "llama-3.2-1b", "meta-llama/Llama-3.2-3B": "llama-3.2-3b",
+              "meta-llama/Meta-Llama-3-8B": "llama-3-8b", "meta-llama/Llama-3-8B": "llama-3-8b"}
+
+
+def _synthetic(preset: str, device: str, embed_from=None, seed: int = 0, flip_fraction: float = 0.2) -> W.ModelWeights:
+    cfg = _PRESETS[preset]
+    make = W.synthetic_llama if cfg.arch == W.ARCH_LLAMA else W.synthetic_gpt2
+    if embed_from is not None:
+        return make(cfg, seed=seed, device=device, embed_from=embed_from, flip_fraction=flip_fraction)
+    return make(cfg, seed=seed, device=device)
+
+
+def _named_checkpoint(name: str) -> Optional[str]:
+    """$SPECDEC_MODEL_DIR/<name> (also with the hub organisation stripped) when that directory exists."""
+    import os
+
+    root = os.environ.get("SPECDEC_MODEL_DIR")
+    if not root:
+        return None
+    for cand in (name, name.split("/")[-1]):
+        p = os.path.join(root, cand)
+        if os.path.isdir(p):
+            return p
+    return None
+
+
+def create_hip_pair(base_spec: Any, draft_spec: Any, device: str = "cuda", **kw) -> Tuple["HipLM", "HipLM"]:
+    """Target and draft of a pipeline from its two config entries. When both are model NAMES without a local checkpoint (the
+    reference's YAMLs name hub models: `gpt2` / `distilgpt2`), the synthetic pair is built TOGETHER — the draft shares the
+    target's token tables and most of its successor structure (specdec_hip.weights), as bench.py's pair does — instead of two
+    unrelated random models whose acceptance would be zero."""
+    both_named = all(isinstance(s, str) and (s in _HUB_NAMES or s.startswith("synthetic:")) and _named_checkpoint(s) is None
+                     for s in (base_spec, draft_spec))
+    if not both_named:
+        return create_hip_lm(base_spec, device=device, **kw), create_hip_lm(draft_spec, device=device, **kw)
+    names = [s.split(":", 1)[1] if s.startswith("synthetic:") else _HUB_NAMES[s] for s in (base_spec, draft_spec)]
+    for s in (base_spec, draft_spec):
+        if not s.startswith("synthetic:"):
+            logger.warning("model %r: nothing is downloaded by name and $SPECDEC_MODEL_DIR/%s does not exist — using architecture-exact "
+                           "SYNTHETIC weights of that model's shape (specdec_hip.weights)", s, s)
+    tgt = _synthetic(names[0], device, seed=0)
+    same_family = _PRESETS[names[0]].arch == _PRESETS[names[1]].arch and _PRESETS[names[0]].vocab == _PRESETS[names[1]].vocab
+    drf = _synthetic(names[1], device, embed_from=tgt if same_family else None, seed=1)
+    return HipLM(tgt, device=device, name=str(base_spec), **kw), HipLM(drf, device=device, name=str(draft_spec), **kw)
+
+
 def create_hip_lm(spec: Any, device: str = "cuda", **kw) -> HipLM:
-    """`spec`: a ModelWeights, a local checkpoint directory, or "synthetic:<preset>"."""
+    """`spec`: a ModelWeights, a local checkpoint directory, "synthetic:<preset>", or a hub model name the reference's configs
+    use (`gpt2`, `distilgpt2`, `meta-llama/Llama-3.2-1B`, ...): $SPECDEC_MODEL_DIR/<name> when it exists, else synthetic weights
+    of that architecture with a logged notice. Nothing is downloaded."""
     if isinstance(spec, W.ModelWeights):
         return HipLM(spec, device=device, **kw)
     if isinstance(spec, str) and spec.startswith("synthetic:"):
-        preset = {"llama-3.2-1b": W.LLAMA_3_2_1B, "llama-3.2-3b": W.LLAMA_3_2_3B, "llama-3-8b": W.LLAMA_3_8B}[spec.split(":", 1)[1]]
-        return HipLM(W.synthetic_llama(preset, device=device), device=device, **kw)
+        return HipLM(_synthetic(spec.split(":", 1)[1], device), device=device, **kw)
     import os
+
+    if isinstance(spec, str) and not os.path.isdir(spec) and spec in _HUB_NAMES:
+        local = _named_checkpoint(spec)
+        if local is None:
+            logger.warning("model %r: nothing is downloaded by name and $SPECDEC_MODEL_DIR/%s does not exist — using architecture-exact "
+                           "SYNTHETIC weights of that model's shape (specdec_hip.weights)", spec, spec)
+            return HipLM(_synthetic(_HUB_NAMES[spec], device), device=device, name=spec, **kw)
+        spec = local
 
     if isinstance(spec, str) and os.path.isdir(spec):
         mw = W.load_checkpoint_dir(spec, device=device)

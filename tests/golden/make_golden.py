@@ -534,6 +534,41 @@ def gen_hostlogic():
     print("hostlogic goldens:", {k: len(v) for k, v in out.items()})
 
 
+def gen_fake():
+    """G7: the REFERENCE pipeline exactly as its own configs/specdec.yaml configures it (implementation: fake — the FakeLM test
+    double, src/specdec/models/fake_lm.py:56-106 — base gpt2 / draft distilgpt2 by name, max_draft 4, seed 1234), greedy runs of
+    generate() and generate_batch(), plus the double's own token function on fixed id rows. FakeLM.encode hashes the TEXT
+    (PYTHONHASHSEED-dependent; the generator is run with PYTHONHASHSEED=0), so the prompts' ids are stored and the product is
+    fed ids; the token function hashes a tuple of ints, which CPython does not randomise."""
+    SpeculativePipeline = _reference_pipeline_class()
+    cfg = os.path.join(REF, "configs", "specdec.yaml")
+    out = {"config": "configs/specdec.yaml of the reference, unchanged", "runs": [], "token_function": []}
+    for prompt, n in (("Hello world", 8), ("The quick brown fox", 12), ("a", 5)):
+        pipe = SpeculativePipeline(config_path=cfg)
+        ids = [int(x) for x in pipe.base_lm.encode(prompt)[0].tolist()]
+        rs = pipe.generate(prompt, max_tokens=n, do_sample=False)
+        pipe = SpeculativePipeline(config_path=cfg)
+        rb = pipe.generate_batch([prompt], max_tokens=n, do_sample=False)[0]
+        out["runs"].append({"prompt": prompt, "prompt_ids": ids, "max_tokens": n,
+                            "single": {"generated_tokens": [int(x) for x in rs["generated_tokens"]], "proposed": int(rs["proposed"]),
+                                       "accepted": int(rs["accepted"]), "steps": int(rs["steps"])},
+                            "batch": {"generated_tokens": [int(x) for x in rb["generated_tokens"]], "proposed": int(rb["proposed"]),
+                                      "accepted": int(rb["accepted"]), "steps": int(rb["steps"])}})   # (FakeLM has no tokenizer: generate_batch falls back to generate() per prompt)
+        print("fake", repr(prompt), ids, "->", rs["generated_tokens"], rs["accepted"], "/", rs["proposed"], "| batch", rb["generated_tokens"],
+              rb["accepted"], "/", rb["proposed"])
+    from specdec.models.fake_lm import FakeLM
+
+    lm = FakeLM(model_name="fake-base-gpt2", vocab_size=1000, seed=1234)
+    info = lm.get_tokenizer_info()
+    out["tokenizer_info"] = {k: (int(v) if isinstance(v, int) else v) for k, v in info.items()}
+    for row, k in (([5, 17, 900], 6), ([1, 2, 3, 4], 4), ([999], 3), (list(range(40, 72)), 8), ([0, 0, 0], 12)):
+        toks, logits = lm.generate_tokens(torch.tensor([row]), k)
+        out["token_function"].append({"input_ids": row, "k": k, "tokens": [int(x) for x in toks[0].tolist()], "logits_shape": list(logits.shape)})
+    with open(os.path.join(OUT, "fake_pipeline_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("fake goldens:", len(out["runs"]), "runs,", len(out["token_function"]), "token-function rows")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["kernels"]
@@ -553,3 +588,5 @@ if __name__ == "__main__":
         gen_pipeline_policies()
     if "harness" in which:
         gen_harness()
+    if "fake" in which:
+        gen_fake()
