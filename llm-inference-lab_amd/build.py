@@ -89,7 +89,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if LIB_PATH.exists() and stamp.exists() and stamp.read_text() == want and not force:
         return LIB_PATH
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
-           *map(str, objs), "-o", str(LIB_PATH)]
+           *map(str, objs), "-ldl", "-o", str(LIB_PATH)]   # -ldl: csrc/prefill_gemm.hip opens rocBLAS at first use
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -23,6 +23,7 @@
 
 #include "engine.h"
 #include "persist.h"
+#include "prefill_gemm.h"
 
 struct sd_model {
   sd_model_config cfg;
@@ -64,12 +65,14 @@ struct sd_model {
   unsigned p_gran_parity = 0;
   unsigned* p_sync = nullptr;              // [0] launch counter, [1] status
   unsigned long long* p_debug = nullptr;   // optional timeline (sd_model_probe_persist)
+  void* prefill_ws = nullptr;              // lazily allocated workspace of the GEMM prefill path (csrc/prefill_gemm.hip)
   unsigned* host_status = nullptr;         // pinned host word: a persistent launch that gives up stores its reason here as well
   int persist_cap = 0;                     // tokens per persistent pass this model / device / cache can take (0: none)
   int len_hint = 0;                        // caller's bound on the rows' current lengths (sd_model_set_length_hint; default Lmax)
   int ctx_limit = 0;                       // longest rows the persistent launch serves (kPersistMaxCtx; lifted by SPECDEC_PERSIST_MAX_T)
   ~sd_model() {
     if (host_status) (void)hipHostFree(host_status);
+    if (prefill_ws) (void)hipFree(prefill_ws);
   }
 };
 
@@ -364,6 +367,35 @@ static int forward_pass(sd_model* m, const int32_t* tokens, int tok_stride, cons
   return 0;
 }
 
+// final norm + lm_head + fused argmax over n <= 128 residual rows (bf16 [n][d_model]) -> ids[0..n)
+static int head_pass(sd_model* m, const uint16_t* xrows, int n, int32_t* ids, hipStream_t st) {
+  const sd_model_config& c = m->cfg;
+  GemvArgs h{};
+  h.packed = m->is_packed();
+  h.w8 = m->w8();
+  h.w_scale = m->scale(4 * c.n_layers);
+  h.W = m->mat(4 * c.n_layers, c.lm_head);
+  h.N = c.vocab;
+  h.K = c.d_model;
+  h.n_pairs = (c.vocab + 1) / 2;
+  h.x = xrows;
+  h.x_stride = c.d_model;
+  h.T = n;
+  h.M = n;
+  h.prologue = (c.arch == SD_ARCH_LLAMA) ? PRO_RMSNORM : PRO_LAYERNORM;
+  h.norm_w = c.final_norm_w;
+  h.norm_b = c.final_norm_b;
+  h.norm_eps = c.norm_eps;
+  h.out = nullptr;
+  h.out_dtype = SD_BF16;
+  h.part_val = m->part_val;
+  h.part_idx = m->part_idx;
+  int ks = 1;
+  m->head_grid = gemv_grid(h, &ks);
+  if (int rc = launch_gemv(h, EPI_ARGMAX, st)) return rc;
+  return launch_argmax_finalize(m->part_val, m->part_idx, n, m->head_grid, n, n, ids, st);
+}
+
 // rows [row0, row0+B) of the bound batch; tokens / pos_base / ids_out / logits_out are
 // indexed from row0 (element 0 of each array belongs to row row0)
 static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, const int32_t* pos_base,
@@ -388,7 +420,39 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
     }
     return 0;
   }
-  // long M (prefill): chunks of `cap` positions, one row at a time, in position order
+  // long M (prefill). A prompt of a Llama model with bf16 row-major weights and dense KV is absorbed as GEMMs (csrc/prefill_gemm.hip:
+  // <= 512 positions per chunk, every matrix product one library GEMM, this repo's norm / epilogue / attention kernels around them) when
+  // the caller wants no logits of the prompt positions (skip_head, or ids only — the head then runs over the LAST chunk's rows below).
+  if (M >= kPrefillMinTokens && m->cfg.arch == SD_ARCH_LLAMA && !m->w8() && !m->block_table && !logits_out && m->cfg.weight_dtype == SD_BF16 &&
+      !getenv(debug_env::kNoGemmPrefill) && !m->skip_k && prefill_gemm_available()) {
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_st);
+    if (cap_st == hipStreamCaptureStatusNone) {
+      if (!m->prefill_ws) SD_HIP_CHECK(hipMalloc(&m->prefill_ws, prefill_gemm_workspace_bytes(m->cfg)));
+      PrefillModel pm{&m->cfg, m->k_cache, m->v_cache, m->B, m->Lmax, m->attn_ws, m->attn_cnt};
+      for (int b0 = 0; b0 < B; ++b0) {
+        for (int m0 = 0; m0 < M; m0 += kPrefillChunk) {
+          const int mc = (M - m0 < kPrefillChunk) ? M - m0 : kPrefillChunk;
+          uint16_t* xr = nullptr;
+          if (int rc = prefill_gemm_chunk(pm, tokens + static_cast<size_t>(b0) * tok_stride + m0, pos_base + b0, pos_off + m0, row0 + b0, mc,
+                                          m->prefill_ws, &xr, st))
+            return rc;
+          // the residual rows of the chunk's last <= 128 positions go where every other pass leaves them (hidden rows, the head)
+          const int keep = mc < 128 ? mc : 128;
+          SD_HIP_CHECK(hipMemcpyAsync(m->x, xr + static_cast<size_t>(mc - keep) * m->cfg.d_model, static_cast<size_t>(keep) * m->cfg.d_model * 2,
+                                      hipMemcpyDeviceToDevice, st));
+          if (!skip_head && ids_out) {
+            // ids of the prompt positions: the lm_head over the chunk's rows in groups of <= 128 (the decode-shaped head kernel)
+            for (int s0 = 0; s0 < mc; s0 += 128) {
+              const int n = (mc - s0 < 128) ? mc - s0 : 128;
+              if (int rc = head_pass(m, xr + static_cast<size_t>(s0) * m->cfg.d_model, n, ids_out + static_cast<size_t>(b0) * ids_stride + m0 + s0, st)) return rc;
+            }
+          }
+        }
+      }
+      return 0;
+    }
+  }
   for (int b0 = 0; b0 < B; ++b0) {
     for (int m0 = 0; m0 < M; m0 += cap) {
       const int mc = (M - m0 < cap) ? M - m0 : cap;
