@@ -48,11 +48,23 @@ def _sources() -> list[Path]:
 
 def _digest(src: Path) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(COMMON_FLAGS).encode())
+    h.update(" ".join(_flags_for(src)).encode())
     h.update(src.read_bytes())
     for hdr in sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
         h.update(hdr.read_bytes())
     return h.hexdigest()[:16]
+
+
+# Per-file optimisation level. csrc/persist.hip at -Os: the persistent kernel is one wave per SIMD through ~80 KB of code, every
+# instruction is issued at full latency and the hot paths of a layer barely fit the instruction cache two CUs share; same-box A/B of
+# eight flag sets (profiles/round4_persist_ab.md): -O3 595.6 us per 1B forward, -O2 583.8, -Os 582.3, -align-all-nofallthru-blocks=6
+# 591.4, -align-all-blocks=4 605, the max-ilp / max-memory-clause scheduling strategies 595-596.
+FILE_FLAGS = {"persist.hip": ["-Os"]}
+
+
+def _flags_for(src: Path) -> list[str]:
+    extra = FILE_FLAGS.get(src.name, [])
+    return [f for f in COMMON_FLAGS if not (extra and f == "-O3")] + extra
 
 
 def _compile_one(hipcc: str, src: Path, obj_dir: Path, verbose: bool) -> Path:
@@ -61,7 +73,7 @@ def _compile_one(hipcc: str, src: Path, obj_dir: Path, verbose: bool) -> Path:
         return obj
     for stale in obj_dir.glob(f"{src.stem}.*.o"):
         stale.unlink()
-    cmd = [hipcc, *COMMON_FLAGS, "-x", "hip", "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc, *_flags_for(src), "-x", "hip", "-c", str(src), "-o", str(obj)]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

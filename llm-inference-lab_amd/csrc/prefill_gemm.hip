@@ -104,16 +104,17 @@ __global__ __launch_bounds__(256) void rms_rows_kernel(const uint16_t* x, int x_
 }
 
 // ---- the fused epilogues of the weight-streaming kernels, applied to fp32 products ---------------------------------------------------
-// Y: [T][N] fp32. Block row blockIdx.y handles tokens [128 y, 128 y + 128): GemvArgs carries token counts in 8-bit fields, so every
-// group of 128 tokens gets its own view of the arguments (pos_off and the token-indexed output moved on by 128 tokens) and the
-// epilogue sees token indices below 128 — exactly what it sees in a 128-token pass.
+// Y: [T][N] fp32. GemvArgs carries token counts in 8-bit fields, so every group of 128 tokens gets its own view of the arguments
+// (pos_off and the token-indexed output moved on by 128 tokens) and the epilogue sees token indices below 128 — exactly what it
+// sees in a 128-token pass.
 template <int EPI>
 __global__ __launch_bounds__(256) void epilogue_rows_kernel(GemvArgs a, const float* Y, int T, int out_elem_stride) {
-  const int sub = blockIdx.y;
-  const int t_local = static_cast<int>(threadIdx.x) & 127;
-  const int t = sub * 128 + t_local;
-  const int p = static_cast<int>(blockIdx.x) * 2 + (static_cast<int>(threadIdx.x) >> 7);
-  if (t >= T || p >= a.n_pairs) return;
+  // one token per block row, consecutive threads = consecutive pairs: the fp32 products of a token are read along the row
+  // (pairs of the residual epilogues are adjacent columns, SwiGLU's are (p, p + ff), RoPE's (i, i + D/2) of a head)
+  const int t = blockIdx.y;
+  const int sub = t >> 7, t_local = t & 127;
+  const int p = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x);
+  if (p >= a.n_pairs) return;
   a.pos_off += sub * 128;
   a.out = static_cast<char*>(a.out) + static_cast<size_t>(sub) * 128 * out_elem_stride;
   int r0, r1;
@@ -127,8 +128,7 @@ __global__ __launch_bounds__(256) void epilogue_rows_kernel(GemvArgs a, const fl
 template <int EPI>
 int launch_epilogue_rows(GemvArgs a, const float* Y, int T, int out_elem_stride, hipStream_t st) {
   gemv_derive(a);
-  const int n_sub = (T + 127) / 128;
-  hipLaunchKernelGGL((epilogue_rows_kernel<EPI>), dim3((a.n_pairs + 1) / 2, n_sub), dim3(256), 0, st, a, Y, T, out_elem_stride);
+  hipLaunchKernelGGL((epilogue_rows_kernel<EPI>), dim3((a.n_pairs + 255) / 256, T), dim3(256), 0, st, a, Y, T, out_elem_stride);
   SD_LAUNCH_CHECK();
   return 0;
 }

@@ -1,20 +1,6 @@
 export TMPDIR=/tmp
 O=gpurun_out
-P="python profiles/tools/persist_probe.py --model 1b --tokens 1 --iters 100 --persist-only --no-timeline"
-for rep in 1 2 3; do
-  for v in main al6 al5 alb4 ilp memcl os o2; do
-    if [ $v = main ]; then unset SPECDEC_HIP_LIB; else export SPECDEC_HIP_LIB=_ab_$v/libspecdec_hip.so; fi
-    echo -n "$v rep$rep: "; $P 2>/dev/null | grep "^persistent" | sed 's/persistent  persist_tokens=2 M=1: *//'
-  done
-done > $O/r4_ab_flags.log 2>&1
-unset SPECDEC_HIP_LIB
-cat $O/r4_ab_flags.log
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/r4_prefill_prof -o t -- python3 $GRAFT_REPO_ROOT/profiles/tools/prefill_probe.py 512 > $GRAFT_REPO_ROOT/$O/r4_prefill_prof.log 2>&1; cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import csv, glob, collections
-f = glob.glob('gpurun_out/r4_prefill_prof/**/*kernel_stats.csv', recursive=True)
-print(f)
-rows = list(csv.DictReader(open(f[0])))
-for r in rows[:22]:
-    print(r['Name'][:90], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'])
-PY
+python -m pytest tests/test_hip_prefill_gemm_gpu.py tests/test_hip_persist_gpu.py -q > $O/r4_tests_4.log 2>&1; tail -5 $O/r4_tests_4.log
+timeout -k 10 400 python profiles/tools/prefill_probe.py 32 128 256 512 1024 2048 > $O/r4_prefill_probe_after.log 2>&1; echo rc=$?; grep "^prompt" $O/r4_prefill_probe_after.log
+python bench.py --steps 40 --warmup 5 --cpu-baseline-steps 0 > $O/r4_bench_os.json 2> $O/r4_bench_os.err; python -c "
+import json;d=json.loads(open('gpurun_out/r4_bench_os.json').read().strip().splitlines()[-1]);print('bench', d['ms_per_step'],d['value'],d['step_roofline_frac'],d['roofline']['avg_launch_us'], d['roofline'].get('forward0'))"
