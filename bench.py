@@ -342,7 +342,7 @@ def roofline_leg(sess, B, K, wd, self_draft):
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, FETCH_SIZE x2 on
     # gfx950; profiles/summarize.py): counters cannot be read from inside this process, so the figure comes from the
     # committed summary — and only when that summary was taken with THIS build of the library (content hash)
-    pmc = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "round4_pmc_traffic.json")
     epi = {tm.PROBE_O: 1, tm.PROBE_GATE_UP: 2, tm.PROBE_DOWN: 1, tm.PROBE_LM_HEAD: 4, -1: -1}[top["which"]]
     tt = next(t for t in (1, 2, 3, 5, 9) if top["T"] <= t) if top["T"] <= 9 else None
     if os.path.exists(pmc) and tt is not None and wd == "bf16":
@@ -350,9 +350,9 @@ def roofline_leg(sess, B, K, wd, self_draft):
             tj = json.load(f)
         meta = tj.get("_meta", {})
         if meta.get("lib_sha256") != lib_sha256():
-            roof["traffic_note"] = "profiles/round3_pmc_traffic.json was taken with another build of libspecdec_hip.so: not quoted"
+            roof["traffic_note"] = "profiles/round4_pmc_traffic.json was taken with another build of libspecdec_hip.so: not quoted"
         elif meta.get("workload") != f"{sess.pipe.base_lm.model_name}+{'' if self_draft else sess.pipe.draft_lm.model_name} K={K} B={B}":
-            roof["traffic_note"] = f"profiles/round3_pmc_traffic.json is for {meta.get('workload')!r}: not quoted"
+            roof["traffic_note"] = f"profiles/round4_pmc_traffic.json is for {meta.get('workload')!r}: not quoted"
         else:
             # gate/up and down differ in bytes per launch: pick the entry of this epilogue and token bucket whose bytes are nearest
             prefix = "persist_forward_kernel<" if epi == -1 else f"gemv_mfma_kernel<{epi}, false, {tt}, false"
@@ -360,7 +360,12 @@ def roofline_leg(sess, B, K, wd, self_draft):
             if ks:
                 k_, t = min(ks, key=lambda kv: abs(kv[1]["hbm_bytes_per_launch"] - top["bytes_per_launch"]))
                 roof["traffic"] = t["hbm_bytes_per_launch"]
-                roof["traffic_source"] = f"profiles/round3_pmc_traffic.json [{k_}] (rocprofv3 --pmc passes of bench.py, same library build)"
+                if t.get("avg_us_in_graph"):
+                    # the probe above times the kernel in a loop of its own; inside the step's hipGraph (draft forwards 1..K-1, the
+                    # acceptance pattern's cache lengths) rocprofv3's kernel trace of the same library has it slightly slower
+                    roof["avg_launch_us_in_graph"] = t["avg_us_in_graph"]
+                    roof["frac_in_graph"] = top["bytes_per_launch"] / (t["avg_us_in_graph"] * 1e-6) / HBM_PEAK_BPS
+                roof["traffic_source"] = f"profiles/round4_pmc_traffic.json [{k_}] (rocprofv3 --pmc passes of bench.py, same library build)"
     roof["other_kernels"] = {r["kernel"]: {k: r[k] for k in ("avg_launch_us", "GBps", "launches_per_step", "us_per_step")} for r in rows if r is not top}
     return roof
 

@@ -295,9 +295,9 @@ int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, void* stream,
  * granules) instead of five launches per layer. It replaces the same reference code as sd_model_forward does (the k-step
  * draft loop, src/specdec/models/hf_wrappers.py:417-539). 0 = not available for this model / device (other
  * architectures, fp8 or row-major weights, paged KV, a GPU without 256 CUs, SPECDEC_NO_PERSIST=1); the environment
- * variable SPECDEC_PERSIST_MAX_T (read by sd_model_bind) sets the token limit (default: 2 for models with d_model <= 2048 bound
- * to a cache of <= 1536 positions, where the launch is measured faster than the launch path; 0 for wider models and longer
- * caches, where it is not — one CU walks a head's whole cache; at most 8). */
+ * variable SPECDEC_PERSIST_MAX_T (read by sd_model_bind) sets the token limit (default: 2 for models with d_model <= 2048, where the
+ * launch is measured faster than the launch path; 0 for wider models, where it is not; at most 8). Whether a given pass takes it
+ * also depends on the rows' current length: sd_model_set_length_hint below. */
 int sd_model_persist_tokens(const sd_model* m);
 
 /* Health word of the persistent launches of `m` since it was bound: 0 = every launch ran to completion. Every wait
@@ -329,7 +329,7 @@ int sd_model_set_persist_tokens(sd_model* m, int max_tokens);
 
 /* The caller's bound on the CURRENT length (cached positions) of the rows the coming passes touch; max_len <= 0 or beyond
  * the cache: the cache size (the default after a bind). The persistent launch walks a head's whole cache on one CU and is
- * the faster path up to 1536 positions only, so a session bound for a long context starts on it and moves to the launch
+ * the faster path up to 1280 positions only, so a session bound for a long context starts on it and moves to the launch
  * path when its rows pass that length (host-side state, as above: re-capture after crossing). */
 int sd_model_set_length_hint(sd_model* m, int max_len);
 

@@ -20,6 +20,7 @@ constexpr const char* kNoDirect = "SPECDEC_NO_DIRECT";              // multi-tok
 constexpr const char* kNoPipe = "SPECDEC_NO_PIPE";                  //                     never take gemm_pipe_kernel
 constexpr const char* kNoAttnSplit = "SPECDEC_NO_ATTN_SPLIT";       // attention: never split a row's keys over workgroups (tests of the single-workgroup form)
 constexpr const char* kNoGemmPrefill = "SPECDEC_NO_GEMM_PREFILL";   // prompts always go through the 128-token passes (tests: the two prefill paths against each other)
+constexpr const char* kPrefillMinTokens = "SPECDEC_PREFILL_MIN_TOKENS";   // shortest pass that takes the GEMM prefill path (default kPrefillMinTokens; read once)
 constexpr const char* kMedusaPerHead = "SPECDEC_MEDUSA_PER_HEAD";   // Medusa heads: one launch per head even when they sit at a constant stride
 // ---- measurement hooks (sd_model_probe_gemv) --------------------------------------------------------------------------------
 constexpr const char* kGemvTimeline = "SPECDEC_GEMV_TIMELINE";      // in-kernel 100 MHz stamps of the probed launch, printed to stderr

@@ -80,8 +80,9 @@ namespace sd {
 // One CU (three waves) walks a head's whole cache in the persistent launch, where the launch path splits long rows over up to 32
 // workgroups — 1B dimensions, 1 token, us per forward persistent / launches at 128 ... 4096 cached positions: 588 / 675,
 // 605 / 694, 651 / 721, 723 / 764, 888 / 767, 1186 / 777 (profiles/round3_persist_ab.md): the persistent launch serves rows of
-// up to this many positions.
-constexpr int kPersistMaxCtx = 1536;
+// up to this many positions (where the two lines cross: 723 + 0.161 (L - 1024) against 764 + 0.003 (L - 1024) us at L = 1283;
+// round 4's context sweep: 5.07 ms per step on the persistent launch at 1400-1536 positions against 4.96 on the launch path at 2048).
+constexpr int kPersistMaxCtx = 1280;
 static bool persist_pass_ok(const sd_model* m, int T, int Bc, int Mc) {
   return m->persist_t > 0 && T <= m->persist_t && Mc <= 8 && !m->block_table && Bc * m->cfg.n_heads <= kPersistCUs && m->len_hint <= m->ctx_limit;
 }
@@ -409,21 +410,11 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
   SD_REQUIRE(!logits_out || logits_dtype == SD_F32 || logits_dtype == SD_BF16, "forward: logits dtype %d", logits_dtype);
   const int V = m->cfg.vocab;
   const int cap = (B * M <= m->small_t) ? m->small_t : m->max_t;  // tokens per pass
-  if (M <= cap) {
-    const int Bc = cap / M;
-    for (int b0 = 0; b0 < B; b0 += Bc) {
-      const int nb = (B - b0 < Bc) ? B - b0 : Bc;
-      void* lo = logits_out ? static_cast<char*>(logits_out) + static_cast<size_t>(b0) * M * V * esz : nullptr;
-      if (int rc = forward_pass(m, tokens, tok_stride, pos_base, pos_off, row0, b0, nb, M, ids_out, ids_stride, lo,
-                                logits_dtype, V, skip_head, st))
-        return rc;
-    }
-    return 0;
-  }
-  // long M (prefill). A prompt of a Llama model with bf16 row-major weights and dense KV is absorbed as GEMMs (csrc/prefill_gemm.hip:
+  // A prompt (M >= 96 positions per row, whatever the pass size of the decode-shaped kernels). A prompt of a Llama model with bf16 row-major weights and dense KV is absorbed as GEMMs (csrc/prefill_gemm.hip:
   // <= 512 positions per chunk, every matrix product one library GEMM, this repo's norm / epilogue / attention kernels around them) when
   // the caller wants no logits of the prompt positions (skip_head, or ids only — the head then runs over the LAST chunk's rows below).
-  if (M >= kPrefillMinTokens && m->cfg.arch == SD_ARCH_LLAMA && !m->w8() && !m->block_table && !logits_out && m->cfg.weight_dtype == SD_BF16 &&
+  static const int prefill_min = getenv(debug_env::kPrefillMinTokens) ? atoi(getenv(debug_env::kPrefillMinTokens)) : kPrefillMinTokens;
+  if (M >= prefill_min && m->cfg.arch == SD_ARCH_LLAMA && !m->w8() && !m->block_table && !logits_out && m->cfg.weight_dtype == SD_BF16 &&
       !getenv(debug_env::kNoGemmPrefill) && !m->skip_k && prefill_gemm_available()) {
     hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap_st);
@@ -453,6 +444,18 @@ static int model_forward(sd_model* m, const int32_t* tokens, int tok_stride, con
       return 0;
     }
   }
+  if (M <= cap) {
+    const int Bc = cap / M;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = (B - b0 < Bc) ? B - b0 : Bc;
+      void* lo = logits_out ? static_cast<char*>(logits_out) + static_cast<size_t>(b0) * M * V * esz : nullptr;
+      if (int rc = forward_pass(m, tokens, tok_stride, pos_base, pos_off, row0, b0, nb, M, ids_out, ids_stride, lo,
+                                logits_dtype, V, skip_head, st))
+        return rc;
+    }
+    return 0;
+  }
+  // long M (prefill): chunks of `cap` positions, one row at a time, in position order
   for (int b0 = 0; b0 < B; ++b0) {
     for (int m0 = 0; m0 < M; m0 += cap) {
       const int mc = (M - m0 < cap) ? M - m0 : cap;

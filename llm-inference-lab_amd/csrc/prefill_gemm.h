@@ -6,7 +6,10 @@
 namespace sd {
 
 constexpr int kPrefillChunk = 512;   // positions per GEMM chunk (workspace: ~110 KiB per position at Llama-3.2-3B dimensions)
-constexpr int kPrefillMinTokens = 192;   // shorter passes keep the 128-token decode-shaped kernels (one or two passes of them cost less than the GEMM path's ~14 launches per layer)
+// Shorter passes keep the decode-shaped kernels: the GEMM path's ~14 launches per layer cost ~4.5 ms for the 3B + 1B pair before the
+// first product (160 tokens 5.9 ms, 192 6.2, 256 6.4, 512 8.9), the decode-shaped passes 5.0 / 7.1 / 9.3 ms at 64 / 96 / 128 tokens
+// (profiles/round4_context_scaling.md): they cross below 96.
+constexpr int kPrefillMinTokens = 96;
 
 struct PrefillModel {
   const sd_model_config* cfg;

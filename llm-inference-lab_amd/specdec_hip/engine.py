@@ -261,7 +261,7 @@ class HipModel:
 
     def set_length_hint(self, max_len: Optional[int]) -> None:
         """The caller's bound on the current length of the rows the coming passes touch (None: the cache size). The persistent
-        launch serves rows of up to 1536 positions (sd_model_set_length_hint)."""
+        launch serves rows of up to 1280 positions (sd_model_set_length_hint)."""
         _abi.check(self.lib.sd_model_set_length_hint(self.handle, int(max_len or 0)), "sd_model_set_length_hint")
 
     def health(self) -> int:

@@ -34,7 +34,7 @@ import yaml
 
 from specdec_hip.engine import EngineGaveUp, HipModel, HipSpecDec
 
-from ..models.hip_lm import HipLM, create_hip_lm, create_hip_pair
+from ..models.hip_lm import HipLM, create_hip_lm, create_hip_pair, is_named_pair
 from ..policies.controllers import create_controller
 from ..policies.policies import create_policy
 from ..utils.deterministic import ensure_deterministic, set_deterministic_mode
@@ -148,7 +148,7 @@ class SpeculativePipeline:
             self.base_lm = base_lm if base_lm is not None else None
         no_draft = mode in ("medusa", "eagle") and draft_lm is None and self.config.get("draft_model") in (None, "", "none", "NONE")
         if not self._fake:
-            if base_lm is None and draft_lm is None and not no_draft:
+            if base_lm is None and draft_lm is None and not no_draft and is_named_pair(self.config["base_model"], self.config["draft_model"]):
                 self.base_lm, self.draft_lm = create_hip_pair(self.config["base_model"], self.config["draft_model"])
             else:
                 self.base_lm = base_lm if base_lm is not None else create_hip_lm(self.config["base_model"])
@@ -762,7 +762,7 @@ class DecodeSession:
 
         self._queue = deque()                # launched, not yet consumed: (launch index, set of rows it is void for)
         self._flagged: Dict[int, str] = {}   # rows whose device state must be repaired before the next launch
-        # The persistent draft forward serves rows of up to 1536 positions (one CU walks a head's whole cache); a session whose
+        # The persistent draft forward serves rows of up to 1280 positions (one CU walks a head's whole cache); a session whose
         # cache is sized for more starts on it all the same: every launch point tells the engines how far the rows can have
         # got by the end of the step (sd_model_set_length_hint), and when that moves a model to the other path the queue is
         # drained once and the step captured again (the captured kernels are correct at any length, only slower past the bound).

@@ -126,7 +126,7 @@ class HipLM(LanguageModel):
                 raise ValueError("generate_tokens(row=...) takes one sequence")
             return self._generate_row(ids, max_new_tokens, row0, int(kwargs.get("rows") or row0 + 1))
         m = self._engine(B, L + max_new_tokens + 1)
-        m.set_length_hint(L + max_new_tokens + 1)    # rows of this call stay below it: persistent 1-token passes up to 1536 positions
+        m.set_length_hint(L + max_new_tokens + 1)    # rows of this call stay below it: persistent 1-token passes up to 1280 positions
         host = ids.cpu().tolist()
         dev = self._device
         out_ids, out_logits = [], []
@@ -354,14 +354,20 @@ def _named_checkpoint(name: str) -> Optional[str]:
     return None
 
 
+def is_named_pair(base_spec: Any, draft_spec: Any) -> bool:
+    """Both entries name a known architecture (a hub name of the reference's configs, or "synthetic:<preset>") and neither has a
+    local checkpoint: the case in which the two synthetic models are built together."""
+    def known(s):
+        return isinstance(s, str) and (s in _HUB_NAMES or (s.startswith("synthetic:") and s.split(":", 1)[1] in _PRESETS)) and _named_checkpoint(s) is None
+    return known(base_spec) and known(draft_spec)
+
+
 def create_hip_pair(base_spec: Any, draft_spec: Any, device: str = "cuda", **kw) -> Tuple["HipLM", "HipLM"]:
     """Target and draft of a pipeline from its two config entries. When both are model NAMES without a local checkpoint (the
     reference's YAMLs name hub models: `gpt2` / `distilgpt2`), the synthetic pair is built TOGETHER — the draft shares the
     target's token tables and most of its successor structure (specdec_hip.weights), as bench.py's pair does — instead of two
     unrelated random models whose acceptance would be zero."""
-    both_named = all(isinstance(s, str) and (s in _HUB_NAMES or s.startswith("synthetic:")) and _named_checkpoint(s) is None
-                     for s in (base_spec, draft_spec))
-    if not both_named:
+    if not is_named_pair(base_spec, draft_spec):
         return create_hip_lm(base_spec, device=device, **kw), create_hip_lm(draft_spec, device=device, **kw)
     names = [s.split(":", 1)[1] if s.startswith("synthetic:") else _HUB_NAMES[s] for s in (base_spec, draft_spec)]
     for s in (base_spec, draft_spec):

@@ -50,7 +50,9 @@ def main():
             if f and w:
                 rd, wr = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
                 tr[key[0].split("(")[0]] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_x2_corrected": rd, "write_bytes": wr,
-                                            "launches_counted": len(f)}
+                                            "launches_counted": len(f),
+                                            # average duration of the same kernel in the UN-profiled kernel trace of the bench's graph (us)
+                                            "avg_us_in_graph": sum(agg[key]) / len(agg[key]) / 1e3, "launches_traced": len(agg[key])}
         if len(sys.argv) > 5:   # stamp: content hash of the library the counters were taken with + the workload
             import hashlib
 

@@ -27,6 +27,7 @@ file in profiles/round3 logs and in DESIGN section 4) and the greedy runs are as
 needs (1B: token 7, 3B: token 14)."""
 
 import dataclasses
+import os
 
 import pytest
 import torch
@@ -40,11 +41,14 @@ pytestmark = pytest.mark.gpu
 MODELS = {
     # name: (config, weight dtype, tokens of the greedy run)
     "llama-3.2-1b-16L": (W.LLAMA_3_2_1B, "bf16", 16),
-    "llama-3.2-3b-28L": (W.LLAMA_3_2_3B, "bf16", 18),
+    "llama-3.2-3b-28L": (W.LLAMA_3_2_3B, "bf16", 16),
     "llama-3-8b-32L-bf16": (W.LLAMA_3_8B, "bf16", 6),
-    "llama-3-8b-32L-fp8": (W.LLAMA_3_8B, "fp8", 6),
+    "llama-3-8b-32L-fp8": (W.LLAMA_3_8B, "fp8", 4),
 }
 PREFIX, NEW = 12, 3
+# Llama-3-8B x 32 layers in bf16: the same kernels, depth and oracle cost as the fp8 case below it (which adds the fp8 stream); kept
+# out of the default run so that the driver's `-m gpu` step stays well inside its limit (round 3: 602 of 900 s)
+SLOW = {"llama-3-8b-32L-bf16"}
 
 
 def _truncate(mw: W.ModelWeights, depth: int) -> W.ModelWeights:
@@ -63,6 +67,9 @@ def _rel(got, want):
 def test_full_depth_logits_and_first_divergence(name):
     from specdec_hip.engine import HipModel
 
+    if name in SLOW and not os.environ.get("SPECDEC_RUN_SLOW"):
+        pytest.skip(f"{name}: ~45 s of CPU-oracle forwards; the fp8 variant of the same model runs by default (SPECDEC_RUN_SLOW=1 runs both)")
+
     base_cfg, wdt, n_greedy = MODELS[name]
     cfg = dataclasses.replace(base_cfg, max_pos=512)
     L = cfg.n_layers
@@ -74,7 +81,9 @@ def test_full_depth_logits_and_first_divergence(name):
     seq = torch.randint(4, cfg.vocab, (1, PREFIX + NEW), generator=g)
 
     # ---- (a) error against depth
-    depths = [2, L]   # (the CPU oracle's forwards are the slow part of this test)
+    # (the CPU oracle's forwards are the slow part of this test; two layers at these dimensions are tests/test_hip_fullshape_parity_gpu.py's
+    #  subject, so the shallow point is kept for the smallest model only)
+    depths = [2, L] if L <= 16 else [L]
     rows = []
     for d in depths:
         lm = OracleLM(_truncate(mw_cpu, d), "bf16")

@@ -281,21 +281,25 @@ def test_a_launch_that_cannot_complete_gives_up_and_reports(monkeypatch):
 
 
 def test_default_follows_model_width_and_cache_length(monkeypatch):
-    """sd_model_bind's default (engine.hip carve_workspace, by measurement): two tokens per persistent pass for d_model <= 2048 bound to
-    a cache of <= 1536 positions; off for longer caches (one CU walks a head's whole cache: at 2048 positions the launch path's
-    split-KV attention wins) and for wider models; SPECDEC_PERSIST_MAX_T overrides both."""
+    """sd_model_bind's default (engine.hip carve_workspace, by measurement): two tokens per persistent pass for d_model <= 2048, off for
+    wider models; whether a pass takes the persistent launch then follows the caller's bound on the rows' CURRENT length (1280
+    positions: one CU walks a head's whole cache, past that the launch path's split-KV attention wins); SPECDEC_PERSIST_MAX_T
+    overrides both."""
     from specdec_hip.engine import HipModel
 
     monkeypatch.delenv("SPECDEC_PERSIST_MAX_T", raising=False)
     mw = W.synthetic_llama(TOY, seed=4, device="cuda", layer_gain=0.05)
-    assert HipModel(mw, batch=1, l_max=1536).persist_tokens == 2
+    short = HipModel(mw, batch=1, l_max=1280)
+    assert short.persist_tokens == 2 and short.persist_active(1)      # default bound = the cache size
     long = HipModel(mw, batch=1, l_max=1600)
     # (round 4) a longer cache keeps the capability; what decides a pass is the caller's bound on the rows' CURRENT length
     # (sd_model_set_length_hint; default: the cache size), so a session sized for a long context starts on the persistent launch
     assert long.persist_tokens == 2 and not long.persist_active(1)
     long.set_length_hint(700)
     assert long.persist_active(1) and long.persist_active(2) and not long.persist_active(3)
-    long.set_length_hint(1537)
+    long.set_length_hint(1280)
+    assert long.persist_active(1)
+    long.set_length_hint(1281)
     assert not long.persist_active(1)
     long.set_length_hint(None)
     assert not long.persist_active(1)

@@ -186,7 +186,7 @@ def test_loud_refusals():
     from src.specdec import SpeculativePipeline
 
     with pytest.raises(ValueError, match="implementation"):
-        SpeculativePipeline(implementation="fake")
+        SpeculativePipeline(implementation="mps")     # ("fake" is the reference's test double: tests/test_fake_lm.py)
     import specdec
     import src.specdec
 
