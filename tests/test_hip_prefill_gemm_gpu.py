@@ -1,4 +1,4 @@
-"""Prompt prefill as GEMMs (csrc/prefill_gemm.hip: passes of >= 192 tokens of a Llama model with bf16 weights and dense KV — one
+"""Prompt prefill as GEMMs (csrc/prefill_gemm.hip: passes of >= 96 tokens of a Llama model with bf16 weights and dense KV — one
 library GEMM per matrix product of a <= 512-position chunk, this repo's RMSNorm / fused-epilogue / attention kernels around it)
 against (a) the CPU oracle and (b) the 128-token passes of the decode-shaped kernels it replaces for prompts.
 
@@ -35,7 +35,7 @@ def test_gemm_prefill_matches_the_oracle(cfg, L, monkeypatch):
     want, _ = OracleLM(mw, "bf16").forward(seq)
     hm = _model(mw, L + 64)
     zero = torch.zeros(1, dtype=torch.int32, device="cuda")
-    hm.forward(_dev(seq[:, :L]), zero, 0, skip_head=True)                       # GEMM path (L >= 192, no logits asked for)
+    hm.forward(_dev(seq[:, :L]), zero, 0, skip_head=True)                       # GEMM path (L >= 96, no logits asked for)
     pos = torch.tensor([L], dtype=torch.int32, device="cuda")
     ids, got = hm.forward(_dev(seq[:, L:]), pos, 0, want_logits=True)
     w = want[0, L].float()
