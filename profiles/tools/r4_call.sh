@@ -1,5 +1,12 @@
 export TMPDIR=/tmp
 O=gpurun_out
-python -m pytest tests -m gpu -q --durations=8 > $O/r4_tests_full2.log 2>&1; tail -16 $O/r4_tests_full2.log
-bash profiles/tools/final_profiles.sh r4 > $O/r4_final.log 2>&1; tail -3 $O/r4_final.log
-timeout -k 10 300 python profiles/tools/prefill_probe.py 32 64 96 128 256 512 1024 2048 2>/dev/null | grep "^prompt" | cut -c1-175 > $O/r4_prefill_probe_final.log; cat $O/r4_prefill_probe_final.log
+P="python profiles/tools/persist_probe.py --model 1b --tokens 1 --iters 100 --persist-only --no-timeline"
+for r in 1 2 3; do
+  for v in main lead0 lead3; do
+    if [ $v = main ]; then unset SPECDEC_HIP_LIB; else export SPECDEC_HIP_LIB=_ab_$v/libspecdec_hip.so; fi
+    echo "== $v run $r"; $P 2>&1 | grep -E "us|persist" | tail -3
+  done
+done > $O/r4_lead3_ab.log 2>&1
+tail -40 $O/r4_lead3_ab.log
+export SPECDEC_HIP_LIB=_ab_lead3/libspecdec_hip.so
+python -m pytest tests/test_hip_persist_gpu.py -m gpu -q -x > $O/r4_lead3_tests.log 2>&1; tail -5 $O/r4_lead3_tests.log
