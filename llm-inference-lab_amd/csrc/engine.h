@@ -40,6 +40,8 @@ struct SpecState {
 };
 
 int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st);
+int launch_draft_finalize(const float* part_val, const int* part_idx, int grid, int M, int i, int32_t* ids, const SpecState& s,
+                          const int32_t* skip_k, int skip_i, hipStream_t st);
 int launch_medusa_fill(const SpecState& s, hipStream_t st);
 int launch_medusa_rows(const SpecState& s, int32_t* row_idx, hipStream_t st);
 int launch_medusa_commit(const SpecState& s, hipStream_t st);
@@ -48,6 +50,11 @@ int launch_eagle_extrapolate(const void* x, void* H, void* prev, int32_t* has_pr
                              float eps, float alpha, int d, int B, int K, int rms, hipStream_t st);
 int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st);
 int launch_accept_len(const SpecState& s, hipStream_t st);
+int launch_pack_record(const SpecState& s, int32_t* rec_slots, int rec_ints, int32_t* step_counter, const unsigned* draft_status,
+                       const unsigned* target_status, hipStream_t st);
+bool verify_tail_fits(const SpecState& s);
+int launch_verify_tail(const SpecState& s, const float* part_val, const int* part_idx, int grid, int mode, int32_t* rec_slots,
+                       int rec_ints, int32_t* step_counter, const unsigned* draft_status, const unsigned* target_status, hipStream_t st);
 
 // csrc/sample.hip
 struct SampleArgs;

@@ -1014,40 +1014,6 @@ struct sd_specdec {
 
 namespace sd {
 
-// The step record, written straight into pinned host memory (device-accessible). Two slots, selected by the parity
-// of a device-resident step counter, so that the host can still read step s while step s+1 (launched ahead) writes
-// its own. One wave walks the rows, then advances the counter.
-__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, int32_t* rec_slots, int rec_ints, int32_t* step_counter,
-                                                            const unsigned* draft_status, const unsigned* target_status) {
-  const int lane = threadIdx.x;
-  const int K = s.K;
-  const int slot = *step_counter & 1;
-  int32_t* rec = rec_slots + static_cast<size_t>(slot) * s.B * rec_ints;
-  for (int b = 0; b < s.B; ++b) {
-    int32_t* r = rec + static_cast<size_t>(b) * rec_ints;
-    if (lane == 0) {
-      r[0] = s.accept_len[b];
-      r[1] = s.n_new[b];
-      r[2] = s.cur_len[b];
-    }
-    if (lane <= K) {
-      r[3 + lane] = s.new_tok[b * (K + 1) + lane];
-      r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
-    }
-    if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
-    if (lane == 0) r[5 + 3 * K] = s.adaptive ? s.ctl[4 * b + 3] : K;   // proposals that counted for the row in this step
-    // health of the persistent launches (sd_model_engine_status): non-zero = a launch of this or an earlier step gave up
-    if (lane == 0) r[6 + 3 * K] = static_cast<int32_t>((draft_status ? *draft_status : 0u) | (target_status ? *target_status : 0u));
-  }
-  if (s.adaptive) {   // widest row of the next step
-    int ka = 0;
-    for (int b = lane; b < s.B; b += kWave) ka = max(ka, s.active[b] ? s.k_row[b] : 0);
-    for (int off = 32; off > 0; off >>= 1) ka = max(ka, __shfl_xor(ka, off, 64));
-    if (lane == 0) *s.k_active = ka;
-  }
-  if (lane == 0) *step_counter = *step_counter + 1;
-}
-
 // draft tokens of the NEXT step from the heads: d_{i+1} = argmax head_i(final_norm(h)), h = the residual row of the
 // position that produced the last emitted token. Heads the caller packed at a constant stride (sd_specdec_set_medusa)
 // are evaluated by ONE lm_head-shaped launch (grid y = head: same x rows, same geometry, per-head argmax partials) and
@@ -1156,6 +1122,15 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
   // (a pass that is not needed then costs one launch that returns at entry, not 80) — decided per capture, the model may have
   // been re-bound or its persistent passes switched off since the loop was created
   const bool fwd0_select = s->draft && s->st.fwd0_w && B == 1 && persist_pass_ok(s->draft, 2, 1, 2);
+  // a draft forward that is ONE pass leaves the lm_head partials of all its tokens in the model's workspace: ids and the hand-over
+  // of d_{i+1} are then one launch (draft_finalize_kernel) instead of two
+  const bool one_pass_d = s->draft && B * 2 <= s->draft->max_t;
+  const auto finalize = [&](int M, int i, int32_t* ids, const int32_t* skip_k, int skip_i) -> int {
+    if (one_pass_d)
+      return launch_draft_finalize(s->draft->part_val, s->draft->part_idx, s->draft->head_grid, M, i, ids, s->st, skip_k, skip_i, st_d);
+    return 0;
+  };
+  int32_t* const ids_d = one_pass_d ? nullptr : s->st.draft_ids;
   for (int i = 0; s->draft && i < K; ++i) {
     const int M = (i == 0) ? 2 : 1;
     const int32_t* toks = (i == 0) ? s->st.tok2 : s->st.next_tok;
@@ -1169,26 +1144,43 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
       // 1-token pass over `last` alone, whose id lands where the 2-token pass leaves its second one
       s->draft->skip_k = s->st.fwd0_w;
       s->draft->skip_i = 1;
-      rc_f = model_forward(s->draft, toks, 2, s->st.cur_len, -1, 0, B, 2, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+      rc_f = model_forward(s->draft, toks, 2, s->st.cur_len, -1, 0, B, 2, ids_d, 2, nullptr, SD_BF16, 0, st_d);
+      if (!rc_f) rc_f = finalize(2, 0, s->st.draft_ids, s->st.fwd0_w, 1);
       if (!rc_f) {
         s->draft->skip_k = s->st.fwd0_w + 1;
-        rc_f = model_forward(s->draft, toks + 1, 2, s->st.cur_len, 0, 0, B, 1, s->st.draft_ids + 1, 2, nullptr, SD_BF16, 0, st_d);
+        rc_f = model_forward(s->draft, toks + 1, 2, s->st.cur_len, 0, 0, B, 1, ids_d ? ids_d + 1 : nullptr, 2, nullptr, SD_BF16, 0, st_d);
       }
+      if (!rc_f) rc_f = finalize(1, 0, s->st.draft_ids + 1, s->st.fwd0_w + 1, 1);
     } else {
-      rc_f = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, s->st.draft_ids, 2, nullptr, SD_BF16, 0, st_d);
+      rc_f = model_forward(s->draft, toks, M, s->st.cur_len, off, 0, B, M, ids_d, 2, nullptr, SD_BF16, 0, st_d);
+      if (!rc_f) rc_f = finalize(M, i, s->st.draft_ids, s->draft->skip_k, i);
     }
     s->draft->skip_k = nullptr;
     if (rc_f) return rc_f;
-    if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
+    if (!one_pass_d)
+      if (int rc = launch_draft_next(M, i, s->st, st_d)) return rc;
   }
   if (two) {
     SD_HIP_CHECK(hipEventRecord(s->ev_join, st_d));
     SD_HIP_CHECK(hipStreamWaitEvent(st_t, s->ev_join, 0));
   }
   // verify: one forward over (last, d_1..d_K)
-  if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, K + 1, s->st.target_ids,
+  // greedy steps whose verify forward is ONE pass: ids, accept scan, state advance and the step record are one launch over the
+  // lm_head's partials (verify_tail_kernel) instead of three
+  const unsigned* const st_word_d = (s->draft && s->draft->p_sync) ? s->draft->p_sync + 1 : nullptr;
+  const unsigned* const st_word_t = s->target->p_sync ? s->target->p_sync + 1 : nullptr;
+  const bool tail = !s->sample && verify_tail_fits(s->st) && B * (K + 1) <= s->target->max_t;
+  if (int rc = model_forward(s->target, s->st.verify_tok, K + 1, s->st.cur_len, 0, 0, B, K + 1, tail ? nullptr : s->st.target_ids,
                              K + 1, s->sample ? s->logits : nullptr, SD_BF16, 0, st_t))
     return rc;
+  if (tail) {
+    if (int rc = launch_verify_tail(s->st, s->target->part_val, s->target->part_idx, s->target->head_grid, s->mode, s->host_record, s->rec,
+                                    s->step_counter, st_word_d, st_word_t, st_t))
+      return rc;
+    if (!s->heads.empty())
+      if (int rc = enqueue_medusa_heads(s, st_t)) return rc;
+    return 0;
+  }
   if (s->sample) {
     // accept length -> draw the token after the accepted prefix from the stored logits of that position
     if (int rc = launch_accept_len(s->st, st_t)) return rc;
@@ -1197,9 +1189,7 @@ static int enqueue_step(sd_specdec* s, hipStream_t st_t, hipStream_t st_d) {
       return rc;
   }
   if (int rc = launch_accept(s->st, s->mode, s->sample, st_t)) return rc;
-  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(kWave), 0, st_t, s->st, s->host_record, s->rec, s->step_counter,
-                     (s->draft && s->draft->p_sync) ? s->draft->p_sync + 1 : nullptr, s->target->p_sync ? s->target->p_sync + 1 : nullptr);
-  SD_LAUNCH_CHECK();
+  if (int rc = launch_pack_record(s->st, s->host_record, s->rec, s->step_counter, st_word_d, st_word_t, st_t)) return rc;
   // persistent Medusa heads: the proposals of the next step, after the record of this one has left
   if (!s->heads.empty())
     if (int rc = enqueue_medusa_heads(s, st_t)) return rc;

@@ -98,6 +98,32 @@ __global__ void draft_next_kernel(int M, int i, SpecState s) {
   s.next_tok[b] = d;
 }
 
+// The two above as one launch (one wave per token of the draft pass): the lm_head partials of token (b, m) -> draft_ids[b][m],
+// and the row's last token is d_{i+1}. `ids` is draft_ids, or draft_ids + 1 for the 1-token form of forward 0 (whose id lands
+// where the 2-token form leaves its second one). skip_k / skip_i: the words the forward itself was gated on.
+__global__ __launch_bounds__(kWave) void draft_finalize_kernel(const float* part_val, const int* part_idx, int grid, int M, int i,
+                                                               int32_t* ids, SpecState s, const int32_t* skip_k, int skip_i) {
+  SD_SKIP_IF_INACTIVE(skip_k, skip_i);
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int d = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
+  if (lane != 0) return;
+  const int b = t / M, m = t - b * M;
+  ids[b * 2 + m] = d;
+  if (m == M - 1) {
+    s.draft_tok[b * s.K + i] = d;
+    s.verify_tok[b * (s.K + 1) + i + 1] = d;
+    s.next_tok[b] = d;
+  }
+}
+
+int launch_draft_finalize(const float* part_val, const int* part_idx, int grid, int M, int i, int32_t* ids, const SpecState& s,
+                          const int32_t* skip_k, int skip_i, hipStream_t st) {
+  SD_REQUIRE(M >= 1 && M <= 2 && i >= 0 && i < s.K, "draft_finalize: M=%d i=%d", M, i);
+  hipLaunchKernelGGL(draft_finalize_kernel, dim3(s.B * M), dim3(kWave), 0, st, part_val, part_idx, grid, M, i, ids, s, skip_k, skip_i);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 // Medusa-lite with heads tied to (or copied from) the lm_head, greedy (modes/medusa.py:71-186): every head
 // is the lm_head and the draftor re-uses head 0 on the SAME hidden state for all K proposals, so the draft is
 // K copies of the target's own next token (the argmax of the M = 1 forward that precedes this kernel).
@@ -252,9 +278,8 @@ int launch_draft_next(int M, int i, const SpecState& s, hipStream_t st) {
 // The row's state is advanced on the device for the common case so that the next step
 // can be launched without a host round trip; the host re-synchronises a row whenever
 // the reference's host-side rules (EOS cut, de-duplication, budget) say otherwise.
-__device__ __forceinline__ int accept_scan(const SpecState& s, int b, int lane, int& my_t) {
-  const int K = s.K, M = K + 1;
-  my_t = (lane < M) ? s.target_ids[b * M + lane] : -1;
+__device__ __forceinline__ int accept_scan(const SpecState& s, int b, int lane, int my_t) {
+  const int K = s.K;
   const bool match = (lane < K) && (my_t == s.draft_tok[b * K + lane]);
   const unsigned long long m64 = __ballot(match);
   const unsigned long long valid = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
@@ -297,15 +322,15 @@ __device__ __forceinline__ void adaptive_update(const SpecState& s, int b, int a
 
 // sampling mode: the accept length alone, so that the sampler knows which logits row to draw from
 __global__ __launch_bounds__(kWave) void accept_len_kernel(SpecState s) {
-  int my_t;
-  const int a = accept_scan(s, blockIdx.x, threadIdx.x, my_t);
-  if (threadIdx.x == 0) s.accept_len[blockIdx.x] = a;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int my_t = (lane <= s.K) ? s.target_ids[b * (s.K + 1) + lane] : -1;
+  const int a = accept_scan(s, b, lane, my_t);
+  if (lane == 0) s.accept_len[b] = a;
 }
 
-__global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, int use_sampled) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// one wave, one row: my_t = the target's id at verify position `lane` (lanes 0..K)
+__device__ __forceinline__ void accept_row(const SpecState& s, int b, int lane, int my_t, int mode, int use_sampled) {
   const int K = s.K, M = K + 1;
-  int my_t;
   const int a = accept_scan(s, b, lane, my_t);
   // sampled bonus token (pipeline.py:3140-3160 / :3351-3361): the token after the accepted prefix
   // is drawn from the target distribution at that position instead of its argmax
@@ -341,10 +366,105 @@ __global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, in
   }
 }
 
+__global__ __launch_bounds__(kWave) void accept_kernel(SpecState s, int mode, int use_sampled) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  accept_row(s, b, lane, (lane <= s.K) ? s.target_ids[b * (s.K + 1) + lane] : -1, mode, use_sampled);
+}
+
 int launch_accept(const SpecState& s, int mode, int use_sampled, hipStream_t st) {
   SD_REQUIRE(s.K >= 1 && s.K <= 63, "accept: K=%d out of range 1..63", s.K);
   SD_REQUIRE(!use_sampled || (s.sampled && mode == 0), "accept: sampled bonus needs the bonus emit mode");
   hipLaunchKernelGGL(accept_kernel, dim3(s.B), dim3(kWave), 0, st, s, mode, use_sampled);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// The step record, written straight into pinned host memory (device-accessible). Two slots, selected by the parity
+// of a device-resident step counter, so that the host can still read step s while step s+1 (launched ahead) writes
+// its own. One wave walks the rows, then advances the counter.
+struct RecordArgs {
+  int32_t* rec_slots;            // pinned host memory: 2 slots x [B][rec_ints]
+  int rec_ints;
+  int32_t* step_counter;         // device
+  const unsigned* draft_status;  // status words of the persistent launches (null: none)
+  const unsigned* target_status;
+};
+
+__device__ __forceinline__ void record_rows(const SpecState& s, const RecordArgs& ra, int lane) {
+  int32_t* const rec_slots = ra.rec_slots;
+  const int rec_ints = ra.rec_ints;
+  int32_t* const step_counter = ra.step_counter;
+  const unsigned* const draft_status = ra.draft_status;
+  const unsigned* const target_status = ra.target_status;
+  const int K = s.K;
+  const int slot = *step_counter & 1;
+  int32_t* rec = rec_slots + static_cast<size_t>(slot) * s.B * rec_ints;
+  for (int b = 0; b < s.B; ++b) {
+    int32_t* r = rec + static_cast<size_t>(b) * rec_ints;
+    if (lane == 0) {
+      r[0] = s.accept_len[b];
+      r[1] = s.n_new[b];
+      r[2] = s.cur_len[b];
+    }
+    if (lane <= K) {
+      r[3 + lane] = s.new_tok[b * (K + 1) + lane];
+      r[4 + 2 * K + lane] = s.target_ids[b * (K + 1) + lane];
+    }
+    if (lane < K) r[4 + K + lane] = s.draft_tok[b * K + lane];
+    if (lane == 0) r[5 + 3 * K] = s.adaptive ? s.ctl[4 * b + 3] : K;   // proposals that counted for the row in this step
+    // health of the persistent launches (sd_model_engine_status): non-zero = a launch of this or an earlier step gave up
+    if (lane == 0) r[6 + 3 * K] = static_cast<int32_t>((draft_status ? *draft_status : 0u) | (target_status ? *target_status : 0u));
+  }
+  if (s.adaptive) {   // widest row of the next step
+    int ka = 0;
+    for (int b = lane; b < s.B; b += kWave) ka = max(ka, s.active[b] ? s.k_row[b] : 0);
+    for (int off = 32; off > 0; off >>= 1) ka = max(ka, __shfl_xor(ka, off, 64));
+    if (lane == 0) *s.k_active = ka;
+  }
+  if (lane == 0) *step_counter = *step_counter + 1;
+}
+
+__global__ __launch_bounds__(kWave) void pack_record_kernel(SpecState s, RecordArgs ra) { record_rows(s, ra, threadIdx.x); }
+
+int launch_pack_record(const SpecState& s, int32_t* rec_slots, int rec_ints, int32_t* step_counter, const unsigned* draft_status,
+                       const unsigned* target_status, hipStream_t st) {
+  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(kWave), 0, st, s, RecordArgs{rec_slots, rec_ints, step_counter, draft_status, target_status});
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- verify: the three above as ONE launch (greedy steps) ----------------------------------------------------------------
+// The lm_head's per-workgroup partials of the B x (K+1) verify positions -> target_ids, the accept scan and state advance of
+// every row, the step record. One workgroup of up to 16 waves: wave w folds the partials of positions w, w + n_waves, ...
+// (ids through LDS), then waves take rows (accept_row), then wave 0 writes the record — 3 launches of ~4.5 us become one.
+constexpr int kTailMaxTokens = 144;   // B x (K+1) positions the one-workgroup tail takes (16 rows at K = 8); more: the three launches
+__global__ __launch_bounds__(1024) void verify_tail_kernel(SpecState s, const float* part_val, const int* part_idx, int grid, int mode,
+                                                           RecordArgs ra) {
+  __shared__ int ids[kTailMaxTokens];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, nw = blockDim.x / kWave;
+  const int M = s.K + 1, T = s.B * M;
+  for (int t = w; t < T; t += nw) {
+    const int id = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
+    if (lane == 0) {
+      ids[t] = id;
+      s.target_ids[t] = id;
+    }
+  }
+  __syncthreads();
+  for (int b = w; b < s.B; b += nw) accept_row(s, b, lane, (lane < M) ? ids[b * M + lane] : -1, mode, 0);
+  __syncthreads();   // (the rows' state is in global memory: written and read by this one workgroup)
+  if (w == 0) record_rows(s, ra, lane);
+}
+
+bool verify_tail_fits(const SpecState& s) { return s.B * (s.K + 1) <= kTailMaxTokens && s.K <= 63; }
+
+int launch_verify_tail(const SpecState& s, const float* part_val, const int* part_idx, int grid, int mode, int32_t* rec_slots,
+                       int rec_ints, int32_t* step_counter, const unsigned* draft_status, const unsigned* target_status, hipStream_t st) {
+  SD_REQUIRE(verify_tail_fits(s), "verify_tail: B=%d K=%d", s.B, s.K);
+  const int T = s.B * (s.K + 1);
+  const int nw = T < 16 ? T : 16;
+  hipLaunchKernelGGL(verify_tail_kernel, dim3(1), dim3(nw * kWave), 0, st, s, part_val, part_idx, grid, mode,
+                     RecordArgs{rec_slots, rec_ints, step_counter, draft_status, target_status});
   SD_LAUNCH_CHECK();
   return 0;
 }
