@@ -1,6 +1,6 @@
 """Per-step busy/gap breakdown from a rocprofv3 kernel trace of bench.py.
 Usage: python profiles/tools/step_breakdown.py <kernel_trace.csv | results.db> > profiles/<name>.md
-A step is delimited by consecutive accept_kernel launches; the table shows, per kernel kind,
+A step is delimited by consecutive verify_tail_kernel (or, sampling steps, accept_kernel) launches; the table shows, per kernel kind,
 launches per step, the average duration and the average idle gap before the launch (end of the
 previous kernel on the device -> start of this one), taken over the steady-state steps."""
 
@@ -26,7 +26,7 @@ def main():
         rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sd::" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-    cuts = [i for i, e in enumerate(ev) if e[0].startswith("accept_kernel")]
+    cuts = [i for i, e in enumerate(ev) if e[0].startswith(("verify_tail_kernel", "accept_kernel"))]
     steps = [(cuts[i] + 1, cuts[i + 1] + 1) for i in range(len(cuts) - 1)]
     steps = steps[len(steps) // 2:]          # steady state: second half
     per = collections.OrderedDict()
