@@ -17,8 +17,9 @@ dropped or rewound tokens), the row's caches are rebuilt from its sequence.
 `generate_batch(do_sample=True)` samples what the reference samples there — only the token after
 the accepted prefix (`sample_bonus_token_from_logits`, :3156/:3231/:3355; drafting and verification
 stay greedy, :2400/:2645) — inside the same captured step (csrc/sample.hip). `generate(do_sample=True)`
-lets HF sample inside both models from the global torch generator (:1019-1081); that has no
-reproducible restatement and is refused loudly.
+is another rule (:1019-1027, :1217-1224): the draft's proposals and the base token of a zero-accept step are
+drawn by transformers' sampling on torch's global CPU generator, verification is greedy; it runs on the
+host-policy loop and, seeded alike, makes the reference's draws (models/hip_lm.py hf_sampling_probs).
 """
 
 from __future__ import annotations
@@ -381,12 +382,16 @@ class SpeculativePipeline:
         return d_ids, d_logits
 
     def _decode_host_policy(self, prompts: List[List[int]], max_tokens: int, emit_mode: int, step_limit: int,
-                            temperature: float = 0.7):
+                            temperature: float = 0.7, sample_t: Optional[float] = None, sample_kwargs: Optional[Dict[str, Any]] = None):
         """The reference's verification for the logit-threshold policies (speculative_scheduler.py:294-368, policies.py:213-396;
         pipeline.py:1019-1100 and :2397-3030): per row and step, K greedy draft tokens with their logits, the base model's
         OWN K greedy tokens with their logits from the same prefix (K one-token HIP forwards each, over the rows' cached
         prefixes), the policy on the device logits, then the same host rules as the device step. A full acceptance takes
-        the extra base forward the reference takes (:3199-3206)."""
+        the extra base forward the reference takes (:3199-3206).
+        sample_t (generate(do_sample=True), pipeline.py:1019-1027): the draft's tokens are DRAWN at that temperature (a draft that
+        draws EOS is shorter, and `proposed` counts what came back, :1122); verification stays greedy; the one base token of a
+        zero-accept step is drawn too (:1217-1224) — the step's last draw."""
+        skw = dict(sample_kwargs or {})
         t_start = time.time()
         rows = [_Row(list(p)) for p in prompts]
         for r in rows:
@@ -412,25 +417,32 @@ class SpeculativePipeline:
                 if not r.active:
                     continue
                 ids = torch.tensor([r.seq], dtype=torch.long)
+                kb = k   # proposals of this row in this step
                 if medusa:
-                    d_ids, d_logits = self._draft_medusa_random(r.seq, k, temperature, b, n)
+                    d_ids, d_logits = self._draft_medusa_random(r.seq, kb, temperature, b, n)
+                elif sample_t is not None:
+                    d_ids, d_logits = self.draft_lm.generate_tokens(ids, kb, temperature=sample_t, do_sample=True, row=b, rows=n, **skw)
+                    kb = int(d_ids.shape[1])
                 else:
-                    d_ids, d_logits = self.draft_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
-                b_ids, b_logits = self.base_lm.generate_tokens(ids, k, do_sample=False, row=b, rows=n)
+                    d_ids, d_logits = self.draft_lm.generate_tokens(ids, kb, do_sample=False, row=b, rows=n)
+                b_ids, b_logits = self.base_lm.generate_tokens(ids, kb, do_sample=False, row=b, rows=n)
                 a, _info = self.policy.accept_tokens(d_ids, b_ids, d_logits, b_logits)
                 d, t = d_ids[0].tolist(), b_ids[0].tolist()
-                if a == k and emit_mode == HipSpecDec.EMIT_BONUS:
+                if sample_t is not None and a == 0:
+                    fb, _ = self.base_lm.generate_tokens(ids, 1, temperature=sample_t, do_sample=True, row=b, rows=n, **skw)
+                    t[0] = int(fb[0, 0])
+                if a == kb and emit_mode == HipSpecDec.EMIT_BONUS:
                     more, _ = self.base_lm.generate_tokens(torch.tensor([r.seq + t], dtype=torch.long), 1, do_sample=False, row=b, rows=n)
                     t.append(int(more[0, 0]))
                 else:
                     t.append(-1)
                 acc0 = r.accepted
                 if emit_mode == HipSpecDec.EMIT_BONUS:
-                    self._rules_batch(r, k, a, t, max_tokens, eos)
+                    self._rules_batch(r, kb, a, t, max_tokens, eos)
                 else:
-                    self._rules_single(r, k, a, d, t, max_tokens, eos)
+                    self._rules_single(r, kb, a, d, t, max_tokens, eos)
                 r.steps += 1
-                stats["proposed"] += k
+                stats["proposed"] += kb
                 stats["accepted"] += r.accepted - acc0
                 if r.active and r.steps >= step_limit:
                     r.active = False
@@ -518,19 +530,23 @@ class SpeculativePipeline:
         max_tokens = max_tokens or self.config["max_new_tokens"]
         temperature = temperature or self.config["temperature"]
         do_sample = do_sample if do_sample is not None else self.config["do_sample"]
+        sample_t: Optional[float] = None
         if do_sample and not self._fake:   # (the fake double ignores sampling parameters, in the reference as here)
-            raise NotImplementedError(
-                "generate(do_sample=True): the reference lets HF sample inside the draft and the base model from the "
-                "global torch generator (pipeline.py:1019-1081); that is not restated. Use generate_batch(do_sample=True) "
-                "(sampled bonus token, reproducible) or do_sample=False")
+            # pipeline.py:1019-1027 / :1217-1224: the DRAFT's proposals, and the one base token of a zero-accept step, are drawn at the
+            # call's temperature (transformers' sampling on torch's global generator, models/hip_lm.py hf_sampling_probs);
+            # every verification path of the scheduler is greedy (speculative_scheduler.py:192-199, :304-310, :339-345)
+            if self.config.get("draft_mode", "vanilla") in ("medusa", "eagle") or self.policy_name != "longest_prefix":
+                raise NotImplementedError("generate(do_sample=True) is restated for the draft-model mode with the longest_prefix policy")
+            sample_t = float(temperature)
         ids = self._encode(prompt)
         # draft modes are a generate() feature in the reference (pipeline.py:1016-1041); generate_batch always
         # drafts with the draft model
         if self.policy_name == "rejection":
             raise NotImplementedError("policy='rejection' is a generate_batch policy (it emits a correction / bonus token every step)")
-        if self.policy_name != "longest_prefix" or self._medusa_random() or self._fake:
+        if self.policy_name != "longest_prefix" or self._medusa_random() or self._fake or sample_t is not None:
             rows, st = self._decode_host_policy([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
-                                                temperature=float(temperature))
+                                                temperature=float(temperature), sample_t=sample_t,
+                                                sample_kwargs={k: kwargs[k] for k in ("top_k", "top_p") if k in kwargs})
         else:
             rows, st = self._decode([ids], max_tokens, HipSpecDec.EMIT_DRAFT, step_limit=2 * max_tokens,
                                     self_draft=self.config.get("draft_mode") in ("medusa", "eagle"))

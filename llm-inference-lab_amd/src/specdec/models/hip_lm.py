@@ -52,6 +52,31 @@ class IdTokenizer:
         return {"input_ids": ids, "attention_mask": mask}
 
 
+def hf_sampling_probs(logits: torch.Tensor, temperature: float, top_k: Optional[int] = 50, top_p: Optional[float] = None) -> torch.Tensor:
+    """The distribution a `do_sample=True` call of the reference's wrapper draws from when it hands the call to transformers'
+    `generate` (hf_wrappers.py:208-232, the path with KV append off — the configuration of its published runs): scores / T,
+    everything below the k-th largest score to -inf (top_k: the library's sampling default 50 unless the caller passes one; ties
+    with the k-th kept), for top_p < 1 the tokens whose ascending cumulative probability is <= 1 - top_p dropped (at least one
+    kept), softmax. logits [B][V] fp32, computed where the logits live (the callers move them to the host first, so that a seeded
+    run makes the draws of the reference's CPU run)."""
+    s = logits.float() / temperature
+    if top_k:
+        kth = torch.topk(s, min(int(top_k), s.shape[-1]))[0][..., -1, None]
+        s = s.masked_fill(s < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(s, descending=False)
+        remove = sorted_logits.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - top_p)
+        remove[..., -1:] = False
+        s = s.masked_fill(remove.scatter(1, sorted_idx, remove), float("-inf"))
+    return torch.softmax(s, dim=-1)
+
+
+def _draw(last: torch.Tensor, temperature: float, kwargs) -> torch.Tensor:
+    """One torch.multinomial draw per row on torch's GLOBAL CPU generator (what the reference's CPU run consumes)."""
+    probs = hf_sampling_probs(last.detach().float().cpu(), float(temperature), kwargs.get("top_k", 50), kwargs.get("top_p"))
+    return torch.multinomial(probs, num_samples=1)
+
+
 class HipLM(LanguageModel):
     def __init__(self, weights: W.ModelWeights, tokenizer: Any = None, name: Optional[str] = None,
                  max_len: int = 1024, batch: int = 1, device: str = "cuda", weight_dtype: str = "bf16",
@@ -64,6 +89,7 @@ class HipLM(LanguageModel):
         self.vocab_size = self.config.vocab
         self._tokenizer = tokenizer or IdTokenizer(self.config.vocab, self.config.eos_token_id)
         self._name = name or self.config.name
+        self._eos_id = getattr(self._tokenizer, "eos_token_id", self.config.eos_token_id)   # what a sampling call ends at
         self.weight_dtype = weight_dtype   # "fp8": the engines stream an e4m3 copy of the Linear weights
         self._max_len, self._batch = max_len, batch
         # paged KV (sd_model_bind_paged): engines share a pool of kv_pages pages of kv_page_len positions instead of
@@ -124,7 +150,8 @@ class HipLM(LanguageModel):
         if row0 or kwargs.get("rows"):
             if B != 1:
                 raise ValueError("generate_tokens(row=...) takes one sequence")
-            return self._generate_row(ids, max_new_tokens, row0, int(kwargs.get("rows") or row0 + 1))
+            return self._generate_row(ids, max_new_tokens, row0, int(kwargs.get("rows") or row0 + 1),
+                                      temperature if (do_sample and temperature and temperature > 0) else None, kwargs)
         m = self._engine(B, L + max_new_tokens + 1)
         m.set_length_hint(L + max_new_tokens + 1)    # rows of this call stay below it: persistent 1-token passes up to 1280 positions
         host = ids.cpu().tolist()
@@ -149,21 +176,22 @@ class HipLM(LanguageModel):
             nxt, logits = m.forward(cur, pos, 0, want_logits=True, logits_dtype=torch.float32)
             last = logits[:, 0, :]
             if do_sample and temperature and temperature > 0:
-                probs = torch.softmax(last / temperature, dim=-1)
-                nxt = torch.multinomial(probs, 1).to(torch.int32)
+                nxt = _draw(last, temperature, kwargs).to(dev, torch.int32)
             for b in range(B):
                 self._cached[b].append(int(cur[b, 0]))
             out_ids.append(nxt.long())
             out_logits.append(last)
             cur = nxt.to(torch.int32).contiguous()
             pos = pos + 1
+            if do_sample and self._eos_id is not None and bool((nxt == self._eos_id).all()):
+                break   # transformers' generate ends a sampling call when every row has produced EOS: fewer ids come back
         if not out_ids:
             return (torch.empty((B, 0), dtype=torch.long, device=dev),
                     torch.empty((B, 0, self.vocab_size), dtype=torch.float32, device=dev))
         return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)
 
-    def _generate_row(self, ids: torch.Tensor, k: int, b: int, rows: int):
-        """Greedy generate_tokens of ONE sequence in cache row b (prefix reuse per row)."""
+    def _generate_row(self, ids: torch.Tensor, k: int, b: int, rows: int, sample_t: Optional[float] = None, kwargs=None):
+        """generate_tokens of ONE sequence in cache row b (prefix reuse per row); greedy, or drawn at temperature `sample_t`."""
         L = ids.shape[1]
         m = self._engine(rows, L + k + 1)
         m.set_length_hint(L + k + 1)
@@ -185,11 +213,15 @@ class HipLM(LanguageModel):
         out_ids, out_logits = [], []
         for _ in range(k):
             nxt, logits = m.forward(cur, pos, 0, want_logits=True, logits_dtype=torch.float32, row0=b)
+            if sample_t is not None:
+                nxt = _draw(logits[:, 0, :], sample_t, kwargs or {}).to(dev, torch.int32)
             self._cached[b].append(int(cur[0, 0]))
             out_ids.append(nxt.long())
             out_logits.append(logits[:, 0, :])
             cur = nxt.to(torch.int32).contiguous()
             pos = pos + 1
+            if sample_t is not None and self._eos_id is not None and int(nxt[0, 0]) == self._eos_id:
+                break   # (as transformers' generate: a sampling call ends at EOS)
         if not out_ids:
             return (torch.empty((1, 0), dtype=torch.long, device=dev), torch.empty((1, 0, self.vocab_size), dtype=torch.float32, device=dev))
         return torch.cat(out_ids, dim=1), torch.stack(out_logits, dim=1)

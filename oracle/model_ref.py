@@ -52,6 +52,25 @@ def _inv_freq(cfg) -> torch.Tensor:
     return inv.float()
 
 
+def hf_sampling_probs(logits: torch.Tensor, temperature: float, top_k: Optional[int] = 50, top_p: Optional[float] = None) -> torch.Tensor:
+    """The distribution transformers' `generate(do_sample=True, temperature=T)` draws a token from (the library the reference
+    calls at hf_wrappers.py:232; pinned by tests/golden/pipeline_sampled_golden.json, generated with transformers 5.15):
+    TemperatureLogitsWarper (scores / T) -> TopKLogitsWarper (top_k, the library's sampling default 50 when the model's
+    generation config leaves it unset: everything below the k-th largest score to -inf, ties with it kept) -> TopPLogitsWarper
+    (only for top_p < 1: ascending sort, drop the tokens whose cumulative probability is <= 1 - top_p, keep at least one) ->
+    softmax. logits [B][V]."""
+    s = logits.float() / temperature
+    if top_k:
+        kth = torch.topk(s, min(int(top_k), s.shape[-1]))[0][..., -1, None]
+        s = s.masked_fill(s < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(s, descending=False)
+        remove = sorted_logits.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - top_p)
+        remove[..., -1:] = False
+        s = s.masked_fill(remove.scatter(1, sorted_idx, remove), float("-inf"))
+    return torch.softmax(s, dim=-1)
+
+
 class OracleLM:
     """Decoder forward on CPU with an explicit KV cache (list of per-layer (k, v))."""
 
@@ -184,11 +203,17 @@ class OracleLM:
         return out
 
     # ---- greedy generation, the semantics of HFWrapper._generate_tokens_async -------
-    def generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, reprefill: bool = False):
+    def generate_tokens(self, input_ids: torch.Tensor, max_new_tokens: int, reprefill: bool = False,
+                        do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = 50, top_p: Optional[float] = None,
+                        eos_token_id: Optional[int] = None):
         """hf_wrappers.py:272-627 under greedy decoding: `max_new_tokens` forwards, each
         taking argmax of the last position's logits; returns (ids [B][k], logits [B][k][V]).
         reprefill=True re-feeds the whole prefix every token, as the reference does with
-        KV append off (pipeline.py:1838); the result is the same, the cost is not."""
+        KV append off (pipeline.py:1838); the result is the same, the cost is not.
+        do_sample=True: with KV append off the reference hands the call to transformers' `generate` (hf_wrappers.py:208-232), whose
+        sampling is restated in hf_sampling_probs; one torch.multinomial draw on torch's GLOBAL generator per position. `generate`
+        ends a (one-row) call at the first eos_token_id it produces: fewer than max_new_tokens ids come back, and no further draws
+        are made."""
         cur = input_ids.clone()
         ids, lg = [], []
         past = None
@@ -200,8 +225,13 @@ class OracleLM:
             else:
                 logits, past = self.forward(cur[:, -1:], past)
             last = logits[:, -1, :]
-            nxt = torch.argmax(last, dim=-1)
+            if do_sample:
+                nxt = torch.multinomial(hf_sampling_probs(last, temperature, top_k, top_p), num_samples=1)[:, 0]
+            else:
+                nxt = torch.argmax(last, dim=-1)
             ids.append(nxt)
             lg.append(last)
             cur = torch.cat([cur, nxt.unsqueeze(1)], 1)
+            if eos_token_id is not None and bool((nxt == eos_token_id).all()):
+                break
         return torch.stack(ids, 1), torch.stack(lg, 1)

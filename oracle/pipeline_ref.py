@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from .model_ref import OracleLM
+from .model_ref import OracleLM, hf_sampling_probs
 
 
 def longest_prefix(draft: Sequence[int], target_argmax: Sequence[int]) -> int:
@@ -201,6 +201,7 @@ class OraclePipeline:
         self.reprefill = reprefill
         self.vocab = base.cfg.vocab
         self.trace: List[Dict] = []
+        self.sample_draft: Optional[float] = None   # temperature of a generate(do_sample=True) call
 
     def _propose_and_verify(self, seq: List[int], row: int = 0):
         """draft K greedy tokens from seq (pipeline.py:2397-2462) and the target's greedy
@@ -226,13 +227,19 @@ class OraclePipeline:
             t0, _ = self.base.generate_tokens(ids, 1, reprefill=self.reprefill)
             draft = [int(t0[0, 0])] * k
         else:
-            d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill)
+            # (generate(do_sample=True), pipeline.py:1019-1027: the DRAFT's k tokens are drawn at the call's temperature; every
+            #  verification path of the scheduler is greedy, speculative_scheduler.py:192-199 / :304-310 / :339-345)
+            d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill, do_sample=self.sample_draft is not None,
+                                                  temperature=self.sample_draft or 1.0,
+                                                  eos_token_id=self.eos if self.sample_draft is not None else None)
             draft = d_ids[0].tolist()
+            k = len(draft)   # (a sampled draft that drew EOS is shorter: `proposed` counts draft_tokens.shape[1], pipeline.py:1122)
         if self.reprefill:
             # reference-faithful cost: the base model generates K tokens autoregressively
             # from the same prefix (speculative_scheduler.py:192-199), + the extra forward
             # when everything was accepted (pipeline.py:3199-3206)
-            b_ids, _ = self.base.generate_tokens(ids, k, reprefill=True)
+            b_ids, b_lg = self.base.generate_tokens(ids, k, reprefill=True)
+            self.logits0 = b_lg[0, 0]
             base = b_ids[0].tolist()
             a = longest_prefix(draft, base)
             t = list(base)
@@ -247,6 +254,7 @@ class OraclePipeline:
         # one cached pass over seq + draft: logits at the last K+1 positions
         lg, _ = self.base.forward(torch.tensor([seq + draft], dtype=torch.int64))
         self.last_logits = lg[0, len(seq) - 1 :]     # [K+1][V]: what the sampled bonus token is drawn from
+        self.logits0 = self.last_logits[0]
         t = self.last_logits.argmax(-1).tolist()
         a = longest_prefix(draft, t)
         return draft, t, a
@@ -394,7 +402,18 @@ class OraclePipeline:
         dt = time.time() - t0
         return [self._result(r, dt, len(rows), i) for i, r in enumerate(rows)]
 
-    def generate(self, prompt: Sequence[int], max_tokens: int) -> Dict:
+    def generate(self, prompt: Sequence[int], max_tokens: int, do_sample: bool = False, temperature: float = 0.7) -> Dict:
+        """pipeline.py:893-1413. do_sample=True: the draft model's proposals are sampled (torch's global generator, seeded by
+        the caller), verification stays greedy — accepted draft tokens are the base model's greedy tokens; the draws decide
+        accept lengths, step count and the proposed / accepted counters. One exception, restated in _generate: the token of a
+        zero-accept step is DRAWN from the base model too (pipeline.py:1217-1224)."""
+        self.sample_draft = float(temperature) if do_sample else None
+        try:
+            return self._generate(prompt, max_tokens)
+        finally:
+            self.sample_draft = None
+
+    def _generate(self, prompt: Sequence[int], max_tokens: int) -> Dict:
         r = RowState(seq=[int(x) for x in prompt])
         self.trace = []
         self._next_draft = {}
@@ -404,7 +423,12 @@ class OraclePipeline:
         while len(r.generated) < max_tokens and step < 2 * max_tokens:   # :984-986
             step += 1
             draft, t, a = self._propose_and_verify(r.seq)
-            new = step_rules_single(r, self.k, a, draft, t, max_tokens, self.eos)
+            if self.sample_draft is not None and a == 0:
+                # zero-accept fallback of a sampling call: ONE base token drawn at the call's temperature from the prefix's
+                # logits (pipeline.py:1217-1224 -> hf_wrappers.py:699-716), the step's last draw
+                probs = hf_sampling_probs(self.logits0.unsqueeze(0), self.sample_draft)
+                t = [int(torch.multinomial(probs, num_samples=1)[0, 0])] + list(t[1:])
+            new = step_rules_single(r, len(draft), a, draft, t, max_tokens, self.eos)
             self.trace.append({"step": step, "a": a, "draft": draft, "t": t[: a + 1], "appended": new})
             if not r.active:
                 break

@@ -569,6 +569,52 @@ def gen_fake():
     print("fake goldens:", len(out["runs"]), "runs,", len(out["token_function"]), "token-function rows")
 
 
+def gen_pipeline_sampled():
+    """generate(do_sample=True) of the REFERENCE (pipeline.py:893-1413) on the G8 tiny Llama pairs, CPU, fp32: the draft's
+    proposals are drawn by torch.multinomial on the global CPU generator (hf_wrappers.py:699-716 / :779-785, seeded here right
+    before each call), verification is greedy (speculative_scheduler.py). Stored: the seed, the emitted tokens and the
+    counters the draws decide."""
+    import shutil
+    import tempfile
+
+    os.environ["SPECDEC_ENABLE_KV_APPEND"] = "0"
+    os.environ["SPECDEC_DETERMINISTIC"] = "1"
+    SpeculativePipeline = _reference_pipeline_class()
+    pairs = cases.g8_pairs(torch.float32)
+    tcfg = pairs["structured"][1].config
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="g8s_")
+    try:
+        for pname, (d, t) in pairs.items():
+            ddir, tdir = os.path.join(tmp, pname + "_draft"), os.path.join(tmp, pname + "_target")
+            _save_local_hf_llama(d, ddir)
+            _save_local_hf_llama(t, tdir)
+            out[pname] = {"draft_checksum": cases.weights_checksum(d), "target_checksum": cases.weights_checksum(t), "runs": []}
+            rng = np.random.default_rng(7)
+            for k in (2, 4):
+                pipe = SpeculativePipeline(base_model=tdir, draft_model=ddir, implementation="hf", device="cpu",
+                                           controller="fixed", controller_params={"k": k}, max_draft=k, seed=1234)
+                for seed, temperature, max_tokens, plen in ((11, 0.7, 12, 6), (12, 12.0, 16, 9), (13, 30.0, 12, 5)):
+                    prompt_ids = rng.integers(4, tcfg.vocab, size=plen).tolist()
+                    prompt = " ".join(f"t{i:03d}" for i in prompt_ids)
+                    torch.manual_seed(seed)
+                    rs = pipe.generate(prompt, max_tokens=max_tokens, temperature=temperature, do_sample=True)
+                    rg = pipe.generate(prompt, max_tokens=max_tokens, temperature=temperature, do_sample=False)
+                    out[pname]["runs"].append({
+                        "k": k, "max_tokens": max_tokens, "prompt_ids": prompt_ids, "seed": seed, "temperature": temperature,
+                        "sampled": {"generated_tokens": [int(x) for x in rs["generated_tokens"]], "proposed": int(rs["proposed"]),
+                                    "accepted": int(rs["accepted"]), "steps": int(rs["steps"])},
+                        "greedy": {"generated_tokens": [int(x) for x in rg["generated_tokens"]], "proposed": int(rg["proposed"]),
+                                   "accepted": int(rg["accepted"]), "steps": int(rg["steps"])},
+                    })
+                    print(pname, "k", k, "T", temperature, "sampled", rs["generated_tokens"], rs["accepted"], "/", rs["proposed"], "steps", rs["steps"],
+                          "| greedy", rg["accepted"], "/", rg["proposed"], "steps", rg["steps"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "pipeline_sampled_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["kernels"]
@@ -590,3 +636,5 @@ if __name__ == "__main__":
         gen_harness()
     if "fake" in which:
         gen_fake()
+    if "pipeline_sampled" in which:
+        gen_pipeline_sampled()

@@ -16,10 +16,11 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
 REF = os.environ.get("SPECDEC_REFERENCE", "/root/reference")
-SETS = ["kernels", "hf", "pipeline", "pipeline_eagle", "hostlogic", "medusa", "policies", "harness", "fake"]
+SETS = ["kernels", "hf", "pipeline", "pipeline_eagle", "hostlogic", "medusa", "policies", "harness", "fake", "pipeline_sampled"]
 FILES = ["kernels_golden.json", "kernels_golden.npz", "hf_llama_tiny.json", "hf_llama_tiny.npz", "hf_gpt2_tiny.json",
          "hf_gpt2_tiny.npz", "pipeline_golden.json", "pipeline_eagle_golden.json", "hostlogic_golden.json",
-         "medusa_golden.json", "pipeline_policies_golden.json", "harness_schema_golden.json", "fake_pipeline_golden.json"]
+         "medusa_golden.json", "pipeline_policies_golden.json", "harness_schema_golden.json", "fake_pipeline_golden.json",
+         "pipeline_sampled_golden.json"]
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "specdec")), reason="needs the reference checkout (build container only)")

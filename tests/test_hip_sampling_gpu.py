@@ -209,5 +209,4 @@ def test_sampled_default_config_and_refusals():
     got = pipe.generate_batch(prompts, max_tokens=12, do_sample=True, top_k=None, top_p=0.9)
     want = oracle.generate_batch(prompts, 12, sampling={"temperature": 0.7, "top_k": None, "top_p": 0.9, "seed": 1234})
     assert [r["generated_tokens"] for r in got] == [r["generated_tokens"] for r in want]
-    with pytest.raises(NotImplementedError, match="generate_batch"):
-        pipe.generate(prompts[0], max_tokens=4, do_sample=True)
+    # generate(do_sample=True) is another rule (sampled draft, greedy verification): tests/test_hip_pipeline_gpu.py
