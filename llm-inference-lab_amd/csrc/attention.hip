@@ -42,13 +42,9 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma_kernel(const AttnArgs 
 
 template <int D, int NW, bool PAGED>
 static void launch_attention_one_p(const AttnArgs& a, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;
   const size_t smem = attention_smem_bytes(D, NW);
-  if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<D, NW, PAGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(smem));
-    attr_set = true;
-  }
+  if (smem > 64 * 1024) (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(&attention_mfma_kernel<D, NW, PAGED>), static_cast<int>(smem), attr_set);   // (a failure shows at the launch check)
   hipLaunchKernelGGL((attention_mfma_kernel<D, NW, PAGED>), grid, dim3(NW * 64), smem, st, a);
 }
 

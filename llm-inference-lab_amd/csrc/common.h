@@ -67,6 +67,18 @@ void clear_error();
 // polling of a sticky error only; hipGetLastError is capture-safe.
 #define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
 
+// Dynamic LDS above 64 KiB has to be opted into per kernel AND per device (a process that drives several GPUs sets it on each).
+// `seen`: the call site's static bitmask of the devices it has done. 0 = ok.
+inline int opt_in_dynamic_lds(const void* kernel, int bytes, unsigned long long& seen) {
+  int dev = 0;
+  SD_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !((seen >> dev) & 1ull)) {
+    SD_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 64) seen |= 1ull << dev;
+  }
+  return 0;
+}
+
 inline int dtype_size(int dt) {
   switch (dt) {
     case SD_F32: return 4;

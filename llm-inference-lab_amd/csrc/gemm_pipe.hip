@@ -512,12 +512,8 @@ static int pipe_chunk(int T, int TG, int K, int ksplit, int kw, bool w8, int* sc
 
 template <int EPI, int TG, bool W8, int SC>
 static int launch_pipe_one(const GemvArgs& a, const PipeGeom& pg, int grid, size_t smem, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, TG, W8, SC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&gemm_pipe_kernel<EPI, TG, W8, SC>), 160 * 1024, attr_set)) return rc;
   hipLaunchKernelGGL((gemm_pipe_kernel<EPI, TG, W8, SC>), dim3(grid), dim3(kGemvThreads), smem, st, a, pg);
   SD_LAUNCH_CHECK();
   return 0;

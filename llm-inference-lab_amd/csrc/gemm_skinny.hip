@@ -729,11 +729,8 @@ static int launch_slice_one(const GemvArgs& a, int grid, hipStream_t st) {
   using C = SliceCfg<TG>;
   const size_t smem = static_cast<size_t>(kGemvWaves) * C::REGION + skinny_part_bytes(TG);
   static_assert(static_cast<size_t>(kGemvWaves) * C::REGION + sizeof(float) * kGemvWaves * TG * 256 <= 160 * 1024, "LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_slice_kernel<EPI, TG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&gemm_slice_kernel<EPI, TG>), 160 * 1024, attr_set)) return rc;
   hipLaunchKernelGGL((gemm_slice_kernel<EPI, TG>), dim3(grid), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;
@@ -759,11 +756,8 @@ template <int EPI>
 static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
   const int TG = (a.T + 15) / 16;
   const size_t smem = skinny_part_bytes(TG) + sizeof(float) * kGemvWaves * TG * 32;   // partials + row-statistics scratch, <= 72 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_direct_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;   // (only the 4-tile instance passes 64 KiB)
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&gemm_direct_kernel<EPI, 4>), 80 * 1024, attr_set)) return rc;
   switch (TG) {
     case 1: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 1>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
     case 2: hipLaunchKernelGGL((gemm_direct_kernel<EPI, 2>), dim3(grid), dim3(kGemvThreads), smem, st, a); break;
@@ -776,12 +770,8 @@ static int launch_direct(const GemvArgs& a, int grid, hipStream_t st) {
 
 template <int EPI, int TG, bool W8, int NB>
 static int launch_skinny_one(const GemvArgs& a, const SkinnyGeom& sg, int grid, size_t smem, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG, W8, NB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel<EPI, TG, W8, NB>), 160 * 1024, attr_set)) return rc;
   hipLaunchKernelGGL((gemm_skinny_kernel<EPI, TG, W8, NB>), dim3(grid), dim3(kGemvThreads), smem, st, a, sg);
   SD_LAUNCH_CHECK();
   return 0;

@@ -495,12 +495,8 @@ int gemv_grid(const GemvArgs& a, int* ppw_out) {
 template <int EPI, bool MASK, int TT, bool W8, int KB>
 static int launch_one(const GemvArgs& a, int grid, size_t smem, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into once per kernel
-  static bool attr_set = false;
-  if (!attr_set) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT, W8, KB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // whole LDS of the CU
-    attr_set = true;
-  }
+  static unsigned long long attr_set = 0;
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&gemv_mfma_kernel<EPI, MASK, TT, W8, KB>), 160 * 1024, attr_set)) return rc;  // whole LDS of the CU
   hipLaunchKernelGGL((gemv_mfma_kernel<EPI, MASK, TT, W8, KB>), dim3(grid, a.batch_bytes ? a.n_batch : 1), dim3(kGemvThreads), smem, st, a);
   SD_LAUNCH_CHECK();
   return 0;

@@ -1386,13 +1386,7 @@ template <int D, int HC, bool STAMPS, bool SEL, bool TAPS>
 static int launch_inst(const PersistArgs& a, size_t smem, hipStream_t st) {
   // (the attribute is per device: a process that drives several GPUs sets it on each)
   static unsigned long long attr_set = 0;
-  int dev = 0;
-  SD_HIP_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !((attr_set >> dev) & 1ull)) {
-    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(kLdsBytes)));
-    if (dev >= 0 && dev < 64) attr_set |= 1ull << dev;
-  }
+  if (int rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), static_cast<int>(kLdsBytes), attr_set)) return rc;
   // test hook (tests/test_hip_persist_gpu.py): one workgroup short, so granules are missing and every bounded wait has to expire
   const int grid = getenv(debug_env::kPersistDropWg) ? kPersistCUs - 1 : kPersistCUs;
   hipLaunchKernelGGL((persist_forward_kernel<D, HC, STAMPS, SEL, TAPS>), dim3(grid), dim3(256), smem, st, a);
