@@ -1,3 +1,5 @@
 export TMPDIR=/tmp
 O=gpurun_out
-hipcc -O3 --offload-arch=gfx950 profiles/tools/microbench/stream_floor.hip -o $O/stream_floor && timeout -k 10 300 $O/stream_floor > $O/r4_stream_floor.log 2>&1; cat $O/r4_stream_floor.log; rm -f $O/stream_floor
+python bench.py --steps 5000 --warmup 5 --cpu-baseline-steps 0 --no-probe 2>$O/r4_long.err | tail -1 > $O/r4_long.json; python -c "
+import json; d=json.load(open('$O/r4_long.json')); print({k:d[k] for k in ('ms_per_step','value','steps','resyncs','acceptance_rate','step_roofline_frac')})"
+tail -3 $O/r4_long.err
