@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
 O=gpurun_out
-python -m pytest tests -m gpu -q --durations=60 > $O/r4_tests_full4.log 2>&1; tail -70 $O/r4_tests_full4.log | cut -c1-150
+bash profiles/tools/final_profiles.sh r4 > $O/r4_final.log 2>&1; tail -3 $O/r4_final.log
+bash profiles/tools/secondary_configs.sh > $O/r4_secondary.log 2>&1; tail -16 $O/r4_secondary.log | cut -c1-200
