@@ -103,10 +103,12 @@ __global__ void draft_next_kernel(int M, int i, SpecState s) {
 // where the 2-token form leaves its second one). skip_k / skip_i: the words the forward itself was gated on.
 __global__ __launch_bounds__(kWave) void draft_finalize_kernel(const float* part_val, const int* part_idx, int grid, int M, int i,
                                                                int32_t* ids, SpecState s, const int32_t* skip_k, int skip_i) {
-  SD_SKIP_IF_INACTIVE(skip_k, skip_i);
+  // (the gate word is loaded next to the partials, not in front of them: one memory round trip instead of two in a launch
+  //  that is nothing but latency; a gated-off launch folds stale partials and stores nothing)
+  const int gate = skip_k ? *skip_k : 0x7fffffff;
   const int t = blockIdx.x, lane = threadIdx.x;
   const int d = fold_partials(part_val + static_cast<size_t>(t) * grid, part_idx + static_cast<size_t>(t) * grid, grid, lane);
-  if (lane != 0) return;
+  if (lane != 0 || gate <= skip_i) return;
   const int b = t / M, m = t - b * M;
   ids[b * 2 + m] = d;
   if (m == M - 1) {
