@@ -118,6 +118,25 @@ def test_k_sweep_batch8_rows_are_independent(k):
     assert 0.0 < acc <= (k + 1) / k
 
 
+@pytest.mark.parametrize("rows", [16, 17])
+def test_step_tail_on_both_sides_of_its_one_workgroup_limit(rows):
+    """The greedy step's tail — target ids, accept scan, state advance and step record — is ONE launch (csrc/misc.hip
+    verify_tail_kernel: one workgroup, wave w folds verify positions w, w + 16, ...) while B x (K+1) <= 144 positions, and the three
+    separate launches beyond. 16 rows at K = 8 is the largest step the one-launch tail takes (144 positions, 9 per wave), 17 rows
+    the first it does not; both against the oracle, ragged prompts so that rows finish at different steps (what LongestPrefixPolicy
+    .accept_tokens and the batch rules decide per row, policies.py:156-180, pipeline.py:3059-3292)."""
+    drf, tgt = tiny_pair(flip_fraction=0.25)
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randint(4, tgt.config.vocab, (5 + (i % 7),), generator=g).tolist() for i in range(rows)]
+    pipe = _pipe(drf, tgt, 8)
+    got = pipe.generate_batch(prompts, max_tokens=14 , do_sample=False)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=8, eos_token_id=tgt.config.eos_token_id)
+    want = oracle.generate_batch(prompts, 14)
+    for b in range(rows):
+        assert got[b]["generated_tokens"] == want[b]["generated_tokens"], (rows, b)
+        assert (got[b]["proposed"], got[b]["accepted"]) == (want[b]["proposed"], want[b]["accepted"])
+
+
 def test_ragged_prompts_and_result_keys():
     drf, tgt = tiny_pair()
     g = torch.Generator().manual_seed(4)
