@@ -202,6 +202,7 @@ class OraclePipeline:
         self.vocab = base.cfg.vocab
         self.trace: List[Dict] = []
         self.sample_draft: Optional[float] = None   # temperature of a generate(do_sample=True) call
+        self.sample_kw: Dict = {"top_k": 50, "top_p": None}
 
     def _propose_and_verify(self, seq: List[int], row: int = 0):
         """draft K greedy tokens from seq (pipeline.py:2397-2462) and the target's greedy
@@ -231,7 +232,7 @@ class OraclePipeline:
             #  verification path of the scheduler is greedy, speculative_scheduler.py:192-199 / :304-310 / :339-345)
             d_ids, _ = self.draft.generate_tokens(ids, k, reprefill=self.reprefill, do_sample=self.sample_draft is not None,
                                                   temperature=self.sample_draft or 1.0,
-                                                  eos_token_id=self.eos if self.sample_draft is not None else None)
+                                                  eos_token_id=self.eos if self.sample_draft is not None else None, **self.sample_kw)
             draft = d_ids[0].tolist()
             k = len(draft)   # (a sampled draft that drew EOS is shorter: `proposed` counts draft_tokens.shape[1], pipeline.py:1122)
         if self.reprefill:
@@ -402,12 +403,14 @@ class OraclePipeline:
         dt = time.time() - t0
         return [self._result(r, dt, len(rows), i) for i, r in enumerate(rows)]
 
-    def generate(self, prompt: Sequence[int], max_tokens: int, do_sample: bool = False, temperature: float = 0.7) -> Dict:
+    def generate(self, prompt: Sequence[int], max_tokens: int, do_sample: bool = False, temperature: float = 0.7,
+                 top_k: Optional[int] = 50, top_p: Optional[float] = None) -> Dict:
         """pipeline.py:893-1413. do_sample=True: the draft model's proposals are sampled (torch's global generator, seeded by
         the caller), verification stays greedy — accepted draft tokens are the base model's greedy tokens; the draws decide
         accept lengths, step count and the proposed / accepted counters. One exception, restated in _generate: the token of a
         zero-accept step is DRAWN from the base model too (pipeline.py:1217-1224)."""
         self.sample_draft = float(temperature) if do_sample else None
+        self.sample_kw = {"top_k": top_k, "top_p": top_p}   # (the call's kwargs reach transformers' generate: hf_wrappers.py:230)
         try:
             return self._generate(prompt, max_tokens)
         finally:
@@ -426,7 +429,7 @@ class OraclePipeline:
             if self.sample_draft is not None and a == 0:
                 # zero-accept fallback of a sampling call: ONE base token drawn at the call's temperature from the prefix's
                 # logits (pipeline.py:1217-1224 -> hf_wrappers.py:699-716), the step's last draw
-                probs = hf_sampling_probs(self.logits0.unsqueeze(0), self.sample_draft)
+                probs = hf_sampling_probs(self.logits0.unsqueeze(0), self.sample_draft, **self.sample_kw)
                 t = [int(torch.multinomial(probs, num_samples=1)[0, 0])] + list(t[1:])
             new = step_rules_single(r, len(draft), a, draft, t, max_tokens, self.eos)
             self.trace.append({"step": step, "a": a, "draft": draft, "t": t[: a + 1], "appended": new})

@@ -118,6 +118,28 @@ def test_k_sweep_batch8_rows_are_independent(k):
     assert 0.0 < acc <= (k + 1) / k
 
 
+@pytest.mark.parametrize("kw", [{}, {"top_k": 10}, {"top_p": 0.9}, {"top_k": None, "top_p": 0.7}])
+def test_generate_with_sampling_filters_against_the_oracle(kw):
+    """The sampling filters of generate(do_sample=True) at a vocabulary larger than the default top-k (the reference fixtures have 160
+    entries): the call's top_k / top_p reach the sampler as they reach transformers' generate in the reference
+    (hf_wrappers.py:230 `generate_kwargs.update(kwargs)`); temperature 8 so that the draws leave the greedy path. Device (bf16 weights,
+    host-side probabilities and draws) against the oracle on the same weights under the same seed."""
+    drf, tgt = tiny_pair(flip_fraction=0.25)
+    prompts = synthetic_prompts(2, 9, tgt.config.vocab, seed=77).tolist()
+    pipe = _pipe(drf, tgt, 4)
+    oracle = OraclePipeline(OracleLM(tgt, "bf16"), OracleLM(drf, "bf16"), k=4, eos_token_id=tgt.config.eos_token_id)
+    greedy_like = 0
+    for i, prompt in enumerate(prompts):
+        torch.manual_seed(100 + i)
+        got = pipe.generate(prompt, max_tokens=14, temperature=8.0, do_sample=True, **kw)
+        torch.manual_seed(100 + i)
+        want = oracle.generate(prompt, 14, do_sample=True, temperature=8.0, **{"top_k": 50, "top_p": None, **kw})
+        assert got["generated_tokens"] == want["generated_tokens"], (kw, i)
+        assert (got["proposed"], got["accepted"], got["steps"]) == (want["proposed"], want["accepted"], want["steps"])
+        greedy_like += got["accepted"] == oracle.generate(prompt, 14)["accepted"]
+    assert greedy_like < len(prompts) or kw.get("top_k") == 10, "the draws should leave the greedy path"
+
+
 @pytest.mark.parametrize("rows", [16, 17])
 def test_step_tail_on_both_sides_of_its_one_workgroup_limit(rows):
     """The greedy step's tail — target ids, accept scan, state advance and step record — is ONE launch (csrc/misc.hip
