@@ -12,6 +12,7 @@ is tests/test_hip_fullshape_parity_gpu.py. The step loop mirrored: src/specdec/c
 :984-1275 (generate), drafting through src/specdec/modes/medusa.py:104-186."""
 
 import dataclasses
+import os
 
 import pytest
 import torch
@@ -41,6 +42,11 @@ def test_config4_per_gpu_shape_k4_batch4(wd):
     passes; bf16 and fp8 storage."""
     from src.specdec import HipLM, SpeculativePipeline
 
+    if wd == "fp8" and not os.environ.get("SPECDEC_RUN_SLOW"):
+        # config 4 is a bf16 configuration; its fp8 twin costs another ~27 s of CPU-oracle forwards. fp8 storage under multi-token
+        # passes at full size stays in the default run: tests/test_full_size_gpu.py (3B + 1B, 40-token verify),
+        # tests/test_hip_fullshape_parity_gpu.py (8B shapes), config 5 below
+        pytest.skip("fp8 twin of config 4: SPECDEC_RUN_SLOW=1 runs it")
     drf, tgt = _pair()
     prompts = synthetic_prompts(4, 24, VOCAB).tolist()
     pipe = SpeculativePipeline(base_lm=HipLM(tgt, weight_dtype=wd), draft_lm=HipLM(drf, weight_dtype=wd),
