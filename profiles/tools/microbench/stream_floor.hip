@@ -14,7 +14,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int THREADS, int DEPTH>
 __global__ __launch_bounds__(THREADS) void stream_hop(const u32x4* __restrict__ w, size_t share_vec, const u32x4* __restrict__ x_in, int x_vec,
-                                                       unsigned* __restrict__ x_out) {
+                                                       unsigned* __restrict__ x_out, unsigned rot_vec, unsigned long long* t_end) {
   extern __shared__ u32x4 xs[];
   const int tid = threadIdx.x;
   // x rows of the previous launch: issued first, so that they return first
@@ -22,11 +22,15 @@ __global__ __launch_bounds__(THREADS) void stream_hop(const u32x4* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 4; ++j) { const int i = tid + j * THREADS; xr[j] = x_in[i < x_vec ? i : x_vec - 1]; }
   const u32x4* p = w + static_cast<size_t>(blockIdx.x) * share_vec;
+  // rot_vec != 0: workgroup b walks its share starting rot_vec * b vectors in (wrapping), so that the workgroups do not sit at the
+  // same offset of their equally sized, equally spaced shares at the same time
+  const size_t rot = rot_vec ? (static_cast<size_t>(blockIdx.x) * rot_vec) % share_vec : 0;
+  auto at = [&](size_t k) -> const u32x4* { size_t q = k + rot; if (q >= share_vec) q -= share_vec; return p + q; };
   u32x4 acc = {0u, 0u, 0u, 0u};
   u32x4 buf[DEPTH];
   size_t i = tid;
 #pragma unroll
-  for (int j = 0; j < DEPTH; ++j) buf[j] = __builtin_nontemporal_load(p + (i + static_cast<size_t>(j) * THREADS < share_vec ? i + static_cast<size_t>(j) * THREADS : share_vec - 1));
+  for (int j = 0; j < DEPTH; ++j) buf[j] = __builtin_nontemporal_load(at(i + static_cast<size_t>(j) * THREADS < share_vec ? i + static_cast<size_t>(j) * THREADS : share_vec - 1));
 #pragma unroll
   for (int j = 0; j < 4; ++j) { const int k = tid + j * THREADS; if (k < x_vec) xs[k] = xr[j]; }
   __syncthreads();
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(THREADS) void stream_hop(const u32x4* __restrict__ 
       const size_t k = i + static_cast<size_t>(j) * THREADS;
       acc ^= buf[j] & xs[(k + j) % x_vec];
       const size_t nk = k + static_cast<size_t>(DEPTH) * THREADS;
-      buf[j] = __builtin_nontemporal_load(p + (nk < share_vec ? nk : share_vec - 1));
+      buf[j] = __builtin_nontemporal_load(at(nk < share_vec ? nk : share_vec - 1));
     }
   }
   unsigned v = acc.x ^ acc.y ^ acc.z ^ acc.w;
@@ -49,10 +53,12 @@ __global__ __launch_bounds__(THREADS) void stream_hop(const u32x4* __restrict__ 
     for (int k = 0; k < THREADS / 64; ++k) r ^= red[k];
     x_out[blockIdx.x * 16 + tid] = (r & 0x3f803f80u) | tid;   // (keeps the values small: they are bf16 pairs to the next launch)
   }
+  if (t_end && tid == 0) t_end[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int THREADS, int DEPTH>
-static float run(size_t bytes, int n, int reps, const char* pool, size_t pool_bytes, unsigned* xa, unsigned* xb, int x_bytes, hipStream_t st) {
+static float run(size_t bytes, int n, int reps, const char* pool, size_t pool_bytes, unsigned* xa, unsigned* xb, int x_bytes, hipStream_t st,
+                 unsigned rot_vec = 0, unsigned long long* t_end = nullptr, float* spread_us = nullptr) {
   const int grid = 256;
   const size_t share_vec = bytes / 16 / grid;
   const size_t nbuf = pool_bytes / bytes;
@@ -60,7 +66,7 @@ static float run(size_t bytes, int n, int reps, const char* pool, size_t pool_by
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
   for (int i = 0; i < n; ++i)
     hipLaunchKernelGGL((stream_hop<THREADS, DEPTH>), dim3(grid), dim3(THREADS), x_bytes, st, reinterpret_cast<const u32x4*>(pool + (i % nbuf) * bytes), share_vec,
-                       reinterpret_cast<const u32x4*>((i & 1) ? xb : xa), x_bytes / 16, (i & 1) ? xa : xb);
+                       reinterpret_cast<const u32x4*>((i & 1) ? xb : xa), x_bytes / 16, (i & 1) ? xa : xb, rot_vec, t_end);
   CK(hipStreamEndCapture(st, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -72,6 +78,13 @@ static float run(size_t bytes, int n, int reps, const char* pool, size_t pool_by
     if (ms < best) best = ms;
   }
   CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+  if (t_end && spread_us) {   // end stamps of the LAST launch of the last replay (100 MHz): last workgroup - first workgroup
+    unsigned long long h[256];
+    CK(hipMemcpy(h, t_end, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long lo = h[0], hi = h[0];
+    for (int i = 1; i < 256; ++i) { lo = h[i] < lo ? h[i] : lo; hi = h[i] > hi ? h[i] : hi; }
+    *spread_us = static_cast<float>(hi - lo) / 100.f;
+  }
   return best * 1000.f / n;
 }
 
@@ -99,6 +112,18 @@ int main() {
         default: us = run<1024, 12>(b, n, reps, pool, pool_bytes, xa, xb, x_bytes, st); break;
       }
       printf("%10.2f ", us);
+    }
+    printf("\n");
+  }
+  unsigned long long* t_end; CK(hipMalloc(&t_end, 256 * 8));
+  printf("\nstart offsets rotated per workgroup (512 threads x 8 loads in flight): us per launch (spread of the 256 end stamps of one launch)\n");
+  printf("%-26s %18s %18s %18s %18s\n", "rotation (bytes / workgroup)", "18.9 MB", "31.5 MB", "50.3 MB", "100.7 MB");
+  for (unsigned rot_bytes : {0u, 4096u, 9216u, 33792u, 66560u}) {
+    printf("%-26u ", rot_bytes);
+    for (size_t b : sizes) {
+      float sp = 0;
+      const float us = run<512, 8>(b, n, reps, pool, pool_bytes, xa, xb, x_bytes, st, rot_bytes / 16, t_end, &sp);
+      printf("%9.2f (%6.2f) ", us, sp);
     }
     printf("\n");
   }
