@@ -23,7 +23,7 @@ constexpr const char* kNoGemmPrefill = "SPECDEC_NO_GEMM_PREFILL";   // prompts a
 constexpr const char* kPrefillMinTokens = "SPECDEC_PREFILL_MIN_TOKENS";   // shortest pass that takes the GEMM prefill path (default kPrefillMinTokens; read once)
 constexpr const char* kMedusaPerHead = "SPECDEC_MEDUSA_PER_HEAD";   // Medusa heads: one launch per head even when they sit at a constant stride
 // ---- measurement hooks (sd_model_probe_gemv) --------------------------------------------------------------------------------
-constexpr const char* kGemvTimeline = "SPECDEC_GEMV_TIMELINE";      // in-kernel 100 MHz stamps of the probed launch, printed to stderr
+constexpr const char* kGemvTimeline = "SPECDEC_GEMV_TIMELINE";      // in-kernel 100 MHz stamps of the probed launch, printed to stderr ("2": per workgroup too)
 constexpr const char* kProbeHot = "SPECDEC_PROBE_HOT";              // cycle over n layers only (1: cache-resident weights)
 constexpr const char* kProbeNoXstat = "SPECDEC_PROBE_NO_XSTAT";     // probed launches compute their own row statistics
 

@@ -883,6 +883,13 @@ extern "C" int sd_model_probe_gemv(sd_model* m, int which, int T, int iters, voi
       }
       fprintf(stderr, "  %-10s %7.2f %7.2f %7.2f\n", names[s], mn, sum / (n ? n : 1), mx);
     }
+    if (getenv(debug_env::kGemvTimeline)[0] == '2') {   // per-workgroup: when its K loop and the workgroup itself were done
+      for (int s : {3, 6}) {
+        fprintf(stderr, "[timeline-wg which=%d T=%d %s]", which, T, names[s]);
+        for (int b = 0; b < 256; ++b) fprintf(stderr, " %.2f", h[b * 8] ? (h[b * 8 + s] - t0) / 100.0 : -1.0);
+        fprintf(stderr, "\n");
+      }
+    }
   }
   return 0;
 }
